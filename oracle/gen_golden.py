@@ -1,0 +1,437 @@
+"""
+TEST INFRASTRUCTURE -- generates tests/golden/*.json from the upstream Python reference.
+
+Run in the build container only (needs /root/reference):   python -m oracle.gen_golden
+Every vector is produced by calling the reference's own functions (input.parse_input,
+batching.convert_*, mpi.configure_solve_simulation_problem + the attract / target / simulate
+solvers, attract.attract_master) through oracle/ref_import.py.  Only data is written out:
+YAML inputs, flat network tables, and expected per-problem / aggregated results.
+
+Vector format: see tests/golden/README.md.
+"""
+import os
+import io
+import sys
+import json
+import random
+import logging
+import tempfile
+from math import inf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.ref_import import load_reference  # noqa: E402
+from boolsi_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+R = load_reference()
+Mode = R['constants'].Mode
+NSR = R['constants'].NodeStateRange
+RANGE_CODE = {NSR.MAYBE_FALSE: 0, NSR.MAYBE_TRUE: 1, NSR.TRUE_OR_FALSE: 2, NSR.MAYBE_TRUE_OR_FALSE: 3}
+MODES = {'simulate': Mode.SIMULATE, 'attract': Mode.ATTRACT, 'target': Mode.TARGET}
+
+logging.getLogger().setLevel(logging.ERROR)
+
+DIGEST_SEED = 0xCBF29CE484222325
+M64 = (1 << 64) - 1
+
+
+def code_of(state):
+    return R['model'].encode_state(set(), state)[0]
+
+
+def tt_mask(table, k):
+    mask = 0
+    for row, value in table.items():
+        if value:
+            mask |= 1 << sum(1 << j for j, b in enumerate(row) if b)
+    return mask
+
+
+def t_json(v):
+    return None if v == inf else int(v)
+
+
+def parse_text(text, mode, max_t):
+    with tempfile.NamedTemporaryFile('w', suffix='.yaml', delete=False) as f:
+        f.write(text)
+        path = f.name
+    try:
+        return R['input'].parse_input(path, max_t, MODES[mode])
+    finally:
+        os.unlink(path)
+
+
+def cfg_json(cfg):
+    """Flat description of a parsed input, as the reference produced it."""
+    init, fixed, pert = cfg['origin simulation problem']
+    iv, fv, pv = cfg['simulation problem variations']
+    out = {
+        'node_names': cfg['node names'],
+        'preds': cfg['incoming node lists'],
+        'tt': [str(tt_mask(t, len(p))) for t, p in zip(cfg['truth tables'], cfg['incoming node lists'])],
+        'origin_state': [int(b) for b in init],
+        'origin_fixed': sorted([int(n), int(v)] for n, v in fixed.items()),
+        'origin_pert': sorted([int(t), int(n), int(v)] for t, d in pert.items() for n, v in d.items()),
+        'any_nodes': list(iv),
+        'fixed_var': [[int(n), RANGE_CODE[r]] for n, r in fv],      # heap array order, as parsed
+        'pert_var': [[int(t), int(n), RANGE_CODE[r]] for t, n, r in pv],
+        'n_problems': str(cfg['total combination count']),
+    }
+    if cfg.get('target node set') is not None:
+        out['target_nodes'] = sorted(cfg['target node set'])
+        out['target_code'] = str(cfg['target substate code'])
+    return out
+
+
+def problem_of(cfg, index):
+    """Reference enumeration: index -> (initial_state, fixed_nodes, perturbed_nodes_by_t)."""
+    b = R['batching']
+    radices, places = b.create_numeral_system_from_variations(cfg['simulation problem variations'])
+    digits = b.convert_number_to_variational_representation(index, radices, places)
+    return b.convert_variational_representation_to_simulation_problem(
+        digits, cfg['origin simulation problem'], cfg['simulation problem variations'])
+
+
+def problem_json(problem):
+    init, fixed, pert = problem
+    return {'initial_code': str(code_of(init)),
+            'fixed': sorted([int(n), int(v)] for n, v in fixed.items()),
+            'pert': sorted([int(t), int(n), int(v)] for t, d in pert.items() for n, v in d.items())}
+
+
+def solve_attract(cfg, problem, max_t, max_len, storing_all_states):
+    init, fixed, pert = problem
+    preds, tts = R['model'].adjust_update_rules_for_fixed_nodes(
+        cfg['incoming node lists'], cfg['truth tables'], fixed)
+    a = R['attract']
+    if storing_all_states:
+        from functools import partial
+        solver = partial(a.simulate_until_attractor_or_max_t_storing_all_states, max_len)
+    else:
+        from functools import partial
+        solver = partial(a.simulate_until_attractor_or_max_t_using_reference_points, max_t, max_len,
+                         partial(R['model'].encode_state, set()))
+    solve = R['mpi'].configure_solve_simulation_problem(solver, storing_all_states, max_t, set(), None)
+    res = solve(init, pert, preds, tts)
+    # stop time of the main loop, from a direct call (model.py:152-236)
+    from functools import partial
+    enc = partial(R['model'].encode_state, set())
+    _, _, t_stop, *_ = R['model'].simulate_until_attractor_or_target_substate_or_max_t(
+        storing_all_states, max_t, enc, None, init, pert, preds, tts)
+    if res is None:
+        return [0, '0', 0, 0, int(t_stop)]
+    key, codes, states, traj_l = res
+    return [1, str(key), len(states), int(traj_l), int(t_stop)]
+
+
+def aggregate_rows(rows):
+    """Exact integer aggregation of per-problem rows, in the reference's final order."""
+    table = {}
+    for found, key, length, traj_l, _ in rows:
+        if not found:
+            continue
+        e = table.setdefault(key, [length, 0, 0, 0])
+        e[1] += 1
+        e[2] += traj_l
+        e[3] += traj_l * traj_l
+    order = sorted(table.items(), key=lambda kv: (-kv[1][1], int(kv[0])))
+    return [[k, v[0], v[1], v[2], str(v[3])] for k, v in order]
+
+
+def attract_master_rows(cfg, max_t, max_len, storing_all_states):
+    """End-to-end through the reference's attract_master (single process, in-memory store)."""
+    db = R['zodb'].connection(None)
+    R['attract'].init_attractor_db_structure(db)
+    init, fixed, pert = cfg['origin simulation problem']
+    n = R['attract'].attract_master(
+        R['mpi'].MPICommWrapper(), 4, cfg['origin simulation problem'],
+        cfg['simulation problem variations'], cfg['incoming node lists'], cfg['truth tables'],
+        max_t, max_len, cfg['total combination count'], storing_all_states, db, False, None)
+    rows = []
+    if n:
+        for (neg_freq, key), a in db.root.aggregated_attractors.items():
+            rows.append({'key': str(key), 'length': len(a.states), 'frequency': int(a.frequency),
+                         'mean': float(a.trajectory_l_mean), 'm2': float(a.trajectory_l_variation_sum),
+                         'states': [str(code_of(s)) for s in a.states]})
+    return {'n_attractors': int(n), 'total_frequency': int(db.root.total_frequency()), 'rows': rows}
+
+
+def attract_case(name, text, indices, max_t=inf, max_len=inf, storing_all_states=True, master=False):
+    cfg = parse_text(text, 'attract', max_t)
+    rows = [solve_attract(cfg, problem_of(cfg, i), max_t, max_len, storing_all_states) for i in indices]
+    case = {'name': name, 'mode': 'attract', 'yaml': text, 'cfg': cfg_json(cfg),
+            'max_t': t_json(max_t), 'max_len': t_json(max_len), 'storing_all_states': storing_all_states,
+            'indices': [str(i) for i in indices], 'per_problem': rows, 'aggregate': aggregate_rows(rows)}
+    if master:
+        case['master'] = attract_master_rows(cfg, max_t, max_len, storing_all_states)
+    return case
+
+
+def target_case(name, text, indices, max_t=inf):
+    cfg = parse_text(text, 'target', max_t)
+    from functools import partial
+    rows = []
+    trajectories = {}
+    for i in indices:
+        init, fixed, pert = problem_of(cfg, i)
+        preds, tts = R['model'].adjust_update_rules_for_fixed_nodes(
+            cfg['incoming node lists'], cfg['truth tables'], fixed)
+        enc = partial(R['model'].encode_state, cfg['target node set'])
+        states, _, t_stop, found, reached, _ = \
+            R['model'].simulate_until_attractor_or_target_substate_or_max_t(
+                True, max_t, enc, cfg['target substate code'], init, pert, preds, tts)
+        solve = R['mpi'].configure_solve_simulation_problem(
+            R['target'].simulate_until_target_substate_or_max_t, True, max_t, cfg['target node set'],
+            cfg['target substate code'])
+        res = solve(init, pert, preds, tts)
+        assert (res is not None) == bool(reached)
+        rows.append([int(bool(reached)), int(t_stop)])
+        if reached and len(trajectories) < 8:
+            trajectories[str(i)] = [str(code_of(s)) for s in res]
+    return {'name': name, 'mode': 'target', 'yaml': text, 'cfg': cfg_json(cfg), 'max_t': t_json(max_t),
+            'indices': [str(i) for i in indices], 'per_problem': rows, 'trajectories': trajectories}
+
+
+def digest_of(states, n_words):
+    d = DIGEST_SEED
+    for s in states:
+        c = code_of(s)
+        for w in range(n_words):
+            d = ((d ^ ((c >> (64 * w)) & M64)) * 0x100000001B3) & M64
+    return d
+
+
+def simulate_case(name, text, indices, max_t, n_full=None):
+    cfg = parse_text(text, 'simulate', max_t)
+    from functools import partial
+    n_words = max(1, (len(cfg['node names']) + 63) // 64)
+    finals, digests, full, problems = [], [], {}, []
+    for q, i in enumerate(indices):
+        problem = problem_of(cfg, i)
+        init, fixed, pert = problem
+        preds, tts = R['model'].adjust_update_rules_for_fixed_nodes(
+            cfg['incoming node lists'], cfg['truth tables'], fixed)
+        solve = R['mpi'].configure_solve_simulation_problem(
+            partial(R['simulate'].simulate_until_max_t, max_t), True, max_t, set(), None)
+        states = solve(init, pert, preds, tts)
+        assert len(states) == max_t + 1
+        finals.append(str(code_of(states[-1])))
+        digests.append(str(digest_of(states, n_words)))
+        problems.append(problem_json(problem))
+        if n_full is None or q < n_full:
+            full[str(i)] = [str(code_of(s)) for s in states]
+    return {'name': name, 'mode': 'simulate', 'yaml': text, 'cfg': cfg_json(cfg), 'max_t': int(max_t),
+            'indices': [str(i) for i in indices], 'final': finals, 'digest': digests,
+            'trajectories': full, 'problems': problems}
+
+
+def read_example(name):
+    with io.open(os.path.join('/root/reference/examples', name)) as f:
+        return f.read()
+
+
+def toy_yaml(rules, initial='any', fixed=None, perturbations=None, target=None):
+    names = sorted(rules)
+    out = ['nodes:'] + ['    - {}'.format(n) for n in names]
+    out += ['update rules:'] + ['    {}: {}'.format(n, rules[n]) for n in names]
+    out += ['initial state:']
+    out += ['    {}: {}'.format(n, initial if isinstance(initial, str) else initial[n]) for n in names]
+    if fixed:
+        out += ['fixed nodes:'] + ["    {}: '{}'".format(n, s) for n, s in fixed.items()]
+    if perturbations:
+        out += ['perturbations:']
+        for n, d in perturbations.items():
+            out.append('    {}:'.format(n))
+            out += ["        '{}': '{}'".format(s, times) for s, times in d.items()]
+    if target:
+        out += ['target state:'] + ['    {}: {}'.format(n, target.get(n, 'any')) for n in names]
+    return '\n'.join(out) + '\n'
+
+
+# Toy networks of the reference's test-suite (boolsi/testing_tools.py:14-29): a 5-node ring with
+# two inverters and a 6-node net with `majority`.
+RULES_A = {'A': 'E', 'B': 'A', 'C': 'B', 'D': 'not C', 'E': 'not D'}
+RULES_B = {'A': 'not F', 'B': 'A', 'C': 'not A and B', 'D': 'C and not F',
+           'E': 'not B and majority(not A, not B, D)', 'F': 'not C and E'}
+
+
+def write(name, obj):
+    path = os.path.join(OUT, name)
+    with open(path, 'w') as f:
+        json.dump(obj, f, separators=(',', ':'))
+        f.write('\n')
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def gen_attract_toy():
+    cases = []
+    for label, rules in (('A', RULES_A), ('B', RULES_B)):
+        n = len(rules)
+        text = toy_yaml(rules)
+        for sas in (True, False):
+            for max_t in (inf, 3, 10):
+                for max_len in (inf, 2):
+                    cases.append(attract_case(
+                        'toy{}_sas{}_t{}_a{}'.format(label, int(sas), max_t, max_len), text,
+                        list(range(1 << n)), max_t, max_len, sas, master=(max_t == inf or sas)))
+        # fixed node + perturbations (attract allows only constant states)
+        first = sorted(rules)[0]
+        third = sorted(rules)[2]
+        text2 = toy_yaml(rules, fixed={first: '1'}, perturbations={third: {'0': '1, 4-5'}, first: {'0': '2'}})
+        for sas in (True, False):
+            cases.append(attract_case('toy{}_fixed_pert_sas{}'.format(label, int(sas)), text2,
+                                      list(range(1 << n)), inf, inf, sas, master=True))
+        cases.append(attract_case('toy{}_fixed_pert_t7'.format(label), text2, list(range(1 << n)), 7, inf, True,
+                                  master=True))
+    write('attract_toy.json', cases)
+
+
+def gen_attract_examples():
+    rng = random.Random(1)
+    cases = [
+        attract_case('example2', read_example('example2.yaml'), list(range(8)), master=True),
+        attract_case('example2_r', read_example('example2.yaml'), list(range(8)), storing_all_states=False,
+                     master=True),
+        attract_case('cambium1', read_example('cambium1.yaml'), [0], master=True),
+        attract_case('cambium1_r', read_example('cambium1.yaml'), [0], storing_all_states=False),
+    ]
+    idx = list(range(2048)) + sorted(rng.randrange(1 << 30) for _ in range(1024))
+    cases.append(attract_case('cambium2_slice', read_example('cambium2.yaml'), idx))
+    cases.append(attract_case('cambium2_slice_t8_a1', read_example('cambium2.yaml'), idx[:1024], 8, 1))
+    cases.append(attract_case('cambium2_slice_r', read_example('cambium2.yaml'), idx[:256] + idx[2048:2304],
+                              storing_all_states=False))
+    write('attract_examples.json', cases)
+
+
+def gen_attract_synth():
+    rng = random.Random(2)
+    cases = []
+    idx32 = list(range(1024)) + sorted(rng.randrange(1 << 32) for _ in range(512))
+    cases.append(attract_case('config3_n32', synth.config3_yaml(), idx32, 4096))
+    idx64 = list(range(1024)) + sorted(rng.randrange(1 << 64) for _ in range(512))
+    cases.append(attract_case('northstar_n64', synth.north_star_yaml(), idx64, 4096))
+    cases.append(attract_case('northstar_n64_t12', synth.north_star_yaml(), idx64[:256] + idx64[1024:1280], 12))
+    idx128 = list(range(256)) + sorted(rng.randrange(1 << 128) for _ in range(256))
+    cases.append(attract_case('synth_n128_k2', synth.network_yaml(128, 2, 129), idx128, 4096))
+    idx200 = list(range(64)) + sorted(rng.randrange(1 << 200) for _ in range(64))
+    cases.append(attract_case('synth_n200_k2', synth.network_yaml(200, 2, 200), idx200, 2048))
+    # wider rules (k = 5) and constant fixed nodes / perturbations on a 40-node net
+    text = synth.network_yaml(40, 5, 40, initial={i: str(i & 1) for i in range(12, 40)},
+                              fixed={3: '1', 17: '0'}, perturbations={5: {'1': '2, 6-7'}, 30: {'0': '3'}})
+    cases.append(attract_case('synth_n40_k5_fixed_pert', text, list(range(512)), 300))
+    write('attract_synth.json', cases)
+
+
+def gen_target():
+    rng = random.Random(3)
+    cases = []
+    for label, rules in (('A', RULES_A), ('B', RULES_B)):
+        names = sorted(rules)
+        target = {names[0]: '1', names[-1]: '0'}
+        cases.append(target_case('toy{}_target'.format(label), toy_yaml(rules, target=target),
+                                 list(range(1 << len(names)))))
+        cases.append(target_case('toy{}_target_t2'.format(label), toy_yaml(rules, target=target),
+                                 list(range(1 << len(names))), 2))
+        text = toy_yaml(rules, fixed={names[1]: 'any?', names[2]: '1?'},
+                        perturbations={names[3]: {'any': '2', '0?': '3'}}, target=target)
+        n_problems = (1 << len(names)) * 3 * 2 * 2 * 2
+        cases.append(target_case('toy{}_target_variations'.format(label), text, list(range(n_problems)), 12))
+    text4 = synth.config4_yaml()
+    idx = list(range(256)) + sorted(rng.randrange(1 << 31) for _ in range(768))
+    cases.append(target_case('config4_n64', text4, idx, 1024))
+    write('target.json', cases)
+
+
+def gen_simulate():
+    cases = []
+    for name, t in (('example1.yaml', 5), ('example3.yaml', 10), ('example1_fixed_nodes.yaml', 5),
+                    ('example1_perturbations.yaml', 5)):
+        text = read_example(name)
+        cfg = parse_text(text, 'simulate', t)
+        n = cfg['total combination count']
+        cases.append(simulate_case(name.replace('.yaml', ''), text, list(range(min(n, 64))), t))
+    names = sorted(RULES_B)
+    text = toy_yaml(RULES_B, initial={n: ('any' if i < 3 else '1') for i, n in enumerate(names)},
+                    fixed={names[1]: 'any?', names[4]: '0?'},
+                    perturbations={names[3]: {'any': '2', '1?': '7'}, names[0]: {'any?': '4'}, names[5]: {'1': '3-4'}})
+    cfg = parse_text(text, 'simulate', 20)
+    cases.append(simulate_case('toyB_variations', text, list(range(cfg['total combination count'])), 20,
+                               n_full=40))
+    text5 = synth.config5_yaml(max_t=200, n_any=6)
+    cases.append(simulate_case('config5_n128_t200', text5, list(range(64)), 200, n_full=2))
+    write('simulate.json', cases)
+
+
+def gen_input():
+    """Parsed tables for every example input, plus accept/reject verdicts for malformed inputs."""
+    parsed = []
+    for name in sorted(os.listdir('/root/reference/examples')):
+        if not name.endswith('.yaml'):
+            continue
+        text = read_example(name)
+        for mode, max_t in (('simulate', 100), ('attract', inf), ('target', inf)):
+            try:
+                cfg = parse_text(text, mode, max_t)
+                parsed.append({'name': name, 'mode': mode, 'max_t': t_json(max_t), 'yaml': text,
+                               'cfg': cfg_json(cfg)})
+            except (ValueError, KeyError) as e:
+                parsed.append({'name': name, 'mode': mode, 'max_t': t_json(max_t), 'yaml': text,
+                               'raises': type(e).__name__})
+    for label, text, mode in (('config3', synth.config3_yaml(), 'attract'),
+                              ('config4', synth.config4_yaml(), 'target'),
+                              ('config5', synth.config5_yaml(300, 8), 'simulate'),
+                              ('northstar', synth.north_star_yaml(), 'attract')):
+        cfg = parse_text(text, mode, 300 if mode == 'simulate' else inf)
+        parsed.append({'name': label, 'mode': mode, 'max_t': 300 if mode == 'simulate' else None,
+                       'yaml': text, 'cfg': cfg_json(cfg)})
+
+    from oracle.malformed_inputs import MALFORMED
+    verdicts = []
+    for label, text, mode, max_t in MALFORMED:
+        try:
+            cfg = parse_text(text, mode, max_t)
+            verdicts.append({'name': label, 'mode': mode, 'max_t': t_json(max_t), 'yaml': text,
+                             'raises': None, 'cfg': cfg_json(cfg)})
+        except Exception as e:     # noqa: BLE001
+            kind = 'ValueError' if isinstance(e, ValueError) else type(e).__name__
+            if type(e).__name__ == 'DuplicateKeyError':
+                kind = 'DuplicateKeyError'
+            verdicts.append({'name': label, 'mode': mode, 'max_t': t_json(max_t), 'yaml': text,
+                             'raises': kind})
+    write('input.json', {'parsed': parsed, 'verdicts': verdicts})
+
+
+def gen_enumeration():
+    """index -> problem for mixed radices (batching.py:160-229) on a toy with every variation kind."""
+    names = sorted(RULES_B)
+    text = toy_yaml(RULES_B, initial={n: ('any' if i % 2 == 0 else '0') for i, n in enumerate(names)},
+                    fixed={names[5]: 'any?', names[1]: '0?', names[3]: 'any', names[0]: '1?'},
+                    perturbations={names[2]: {'any?': '3', '1?': '1', '0': '2'}, names[4]: {'any': '1, 5', '0?': '3'}})
+    cfg = parse_text(text, 'simulate', 10)
+    n = cfg['total combination count']
+    rng = random.Random(5)
+    idx = sorted(set(list(range(64)) + [rng.randrange(n) for _ in range(192)] + [n - 1]))
+    write('enumeration.json', {'yaml': text, 'cfg': cfg_json(cfg), 'max_t': 10, 'indices': [str(i) for i in idx],
+                               'problems': [problem_json(problem_of(cfg, i)) for i in idx]})
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['toy', 'examples', 'synth', 'target', 'simulate', 'input', 'enum']
+    if 'toy' in which:
+        gen_attract_toy()
+    if 'examples' in which:
+        gen_attract_examples()
+    if 'synth' in which:
+        gen_attract_synth()
+    if 'target' in which:
+        gen_target()
+    if 'simulate' in which:
+        gen_simulate()
+    if 'input' in which:
+        gen_input()
+    if 'enum' in which:
+        gen_enumeration()
