@@ -1,0 +1,625 @@
+// Host side of the C-ABI (include/bsx.h): handle management, lowering of the network / problem-space
+// tables into the device layout (gather LUT, bit-packed truth-table masks, dense perturbation
+// schedule), launches, and the merge of the device attractor log.  No CPU compute path exists here:
+// every bsx_run_* ends in a gfx950 kernel launch (bsx_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bsx.h"
+#include "bsx_device.h"
+
+namespace bsx {
+hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
+hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
+hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
+hipError_t configure_kernels(int nw, int k, bool lds, size_t shmem);
+}  // namespace bsx
+
+using namespace bsx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+}  // namespace
+
+struct bsx_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop{};
+    std::string error;
+
+    // network
+    bool have_net = false;
+    uint32_t n_nodes = 0, w64 = 0;
+    DevNet net{};
+    bool lut_in_lds = false;
+    size_t shmem = 0;
+    DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
+
+    // problem space
+    bool have_space = false;
+    DevSpace sp{};
+    DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
+
+    DevBuf<Counters> d_ctr;
+};
+
+#define HIPCHK(h, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (h)->error = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return BSX_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+static int fail(bsx_handle h, int status, const std::string& msg) {
+    if (h) h->error = msg;
+    return status;
+}
+
+extern "C" const char* bsx_status_string(int status) {
+    switch (status) {
+        case BSX_OK: return "ok";
+        case BSX_ERR_INVALID: return "invalid argument";
+        case BSX_ERR_NO_DEVICE: return "no gfx950 device";
+        case BSX_ERR_HIP: return "HIP error";
+        case BSX_ERR_UNSUPPORTED: return "unsupported network size";
+        case BSX_ERR_TABLE_FULL: return "result table full";
+        case BSX_ERR_STEP_LIMIT: return "internal step limit reached";
+        case BSX_ERR_STATE: return "network / problem space not set";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* bsx_last_error(bsx_handle h) {
+    return h ? h->error.c_str() : g_create_error.c_str();
+}
+
+extern "C" int bsx_create(bsx_handle* out, int device) {
+    if (!out) return BSX_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return BSX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_create_error = "device index out of range";
+        return BSX_ERR_INVALID;
+    }
+    bsx_engine* h = new bsx_engine();
+    h->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&h->prop, device)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice/hipGetDeviceProperties: ") + hipGetErrorString(e);
+        delete h;
+        return BSX_ERR_NO_DEVICE;
+    }
+    if (std::strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + h->prop.gcnArchName + ", this engine is built for gfx950 only";
+        delete h;
+        return BSX_ERR_NO_DEVICE;
+    }
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+        (e = h->d_ctr.alloc(1)) != hipSuccess) {
+        g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
+        delete h;
+        return BSX_ERR_HIP;
+    }
+    *out = h;
+    return BSX_OK;
+}
+
+extern "C" int bsx_destroy(bsx_handle h) {
+    if (!h) return BSX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return BSX_OK;
+}
+
+extern "C" int bsx_device_info(bsx_handle h, char* name, uint32_t name_cap, uint32_t* compute_units,
+                               uint64_t* global_mem_bytes) {
+    if (!h) return BSX_ERR_INVALID;
+    if (name && name_cap) std::snprintf(name, name_cap, "%s (%s)", h->prop.name, h->prop.gcnArchName);
+    if (compute_units) *compute_units = (uint32_t)h->prop.multiProcessorCount;
+    if (global_mem_bytes) *global_mem_bytes = (uint64_t)h->prop.totalGlobalMem;
+    return BSX_OK;
+}
+
+extern "C" int bsx_synchronize(bsx_handle h) {
+    if (!h) return BSX_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* pred_offsets,
+                               const uint32_t* pred_idx, const uint32_t* tt_word_offsets,
+                               const uint64_t* tt_words) {
+    if (!h) return BSX_ERR_INVALID;
+    if (n_nodes == 0 || !pred_offsets || !tt_word_offsets || !tt_words)
+        return fail(h, BSX_ERR_INVALID, "bsx_set_network: null table or zero nodes");
+    if (n_nodes > BSX_MAX_NODES) return fail(h, BSX_ERR_UNSUPPORTED, "more than BSX_MAX_NODES nodes");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->have_net = false;
+    h->have_space = false;
+
+    const uint32_t nw = n_nodes <= 32 ? 1 : n_nodes <= 64 ? 2 : n_nodes <= 128 ? 4 : 8;
+    uint32_t k_mux = 1;
+    std::vector<uint32_t> wide;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        if (pred_offsets[i + 1] < pred_offsets[i]) return fail(h, BSX_ERR_INVALID, "pred_offsets not monotone");
+        const uint32_t k = pred_offsets[i + 1] - pred_offsets[i];
+        if (k > BSX_MAX_PREDECESSORS) return fail(h, BSX_ERR_UNSUPPORTED, "node with more than BSX_MAX_PREDECESSORS predecessors");
+        if (k && !pred_idx) return fail(h, BSX_ERR_INVALID, "pred_idx is null");
+        for (uint32_t j = pred_offsets[i]; j < pred_offsets[i + 1]; ++j) {
+            if (pred_idx[j] >= n_nodes) return fail(h, BSX_ERR_INVALID, "predecessor index out of range");
+            if (j > pred_offsets[i] && pred_idx[j] <= pred_idx[j - 1])
+                return fail(h, BSX_ERR_INVALID, "predecessors must be strictly ascending");
+        }
+        const uint32_t need_words = k <= 6 ? 1u : (1u << (k - 6));
+        if (tt_word_offsets[i + 1] - tt_word_offsets[i] != need_words)
+            return fail(h, BSX_ERR_INVALID, "truth table of a node must have ceil(2^k / 64) words");
+        if (k > (uint32_t)kMaxMuxK) wide.push_back(i);
+        else k_mux = std::max(k_mux, k);
+    }
+
+    const uint32_t n_chunks = (n_nodes + 7) / 8;
+    std::vector<uint32_t> masks((size_t)(1u << k_mux) * nw, 0);
+    std::vector<uint32_t> lut((size_t)n_chunks * 256 * k_mux * nw, 0);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const uint32_t k = pred_offsets[i + 1] - pred_offsets[i];
+        if (k > (uint32_t)kMaxMuxK) continue;
+        const uint64_t tt = tt_words[tt_word_offsets[i]];
+        for (uint32_t idx = 0; idx < (1u << k_mux); ++idx)      // replicate over the unused high slots
+            if ((tt >> (idx & ((1u << k) - 1))) & 1ull) masks[(size_t)idx * nw + (i >> 5)] |= 1u << (i & 31);
+        for (uint32_t j = 0; j < k; ++j) {
+            const uint32_t p = pred_idx[pred_offsets[i] + j];
+            const uint32_t chunk = p >> 3, bit = p & 7;
+            for (uint32_t v = 0; v < 256; ++v)
+                if ((v >> bit) & 1u)
+                    lut[(((size_t)chunk * 256 + v) * k_mux + j) * nw + (i >> 5)] |= 1u << (i & 31);
+        }
+    }
+    std::vector<uint32_t> wdesc, wpreds, wtt;
+    for (uint32_t i : wide) {
+        const uint32_t k = pred_offsets[i + 1] - pred_offsets[i];
+        wdesc.push_back(i); wdesc.push_back(k);
+        wdesc.push_back((uint32_t)wpreds.size()); wdesc.push_back((uint32_t)wtt.size());
+        for (uint32_t j = pred_offsets[i]; j < pred_offsets[i + 1]; ++j) wpreds.push_back(pred_idx[j]);
+        for (uint32_t w = tt_word_offsets[i]; w < tt_word_offsets[i + 1]; ++w) {
+            wtt.push_back((uint32_t)tt_words[w]);
+            wtt.push_back((uint32_t)(tt_words[w] >> 32));
+        }
+    }
+
+    HIPCHK(h, h->d_lut.upload(lut));
+    HIPCHK(h, h->d_masks.upload(masks));
+    HIPCHK(h, h->d_wide_desc.upload(wdesc));
+    HIPCHK(h, h->d_wide_preds.upload(wpreds));
+    HIPCHK(h, h->d_wide_tt.upload(wtt));
+
+    h->n_nodes = n_nodes;
+    h->w64 = (n_nodes + 63) / 64;
+    h->net.n_nodes = n_nodes;
+    h->net.nw = nw;
+    h->net.k_mux = k_mux;
+    h->net.n_chunks = n_chunks;
+    h->net.lut_words = (uint32_t)lut.size();
+    h->net.n_wide = (uint32_t)wide.size();
+    h->net.lut = h->d_lut.p;
+    h->net.masks = h->d_masks.p;
+    h->net.wide_desc = h->d_wide_desc.p;
+    h->net.wide_preds = h->d_wide_preds.p;
+    h->net.wide_tt = h->d_wide_tt.p;
+
+    // LDS budget: masks (+pad) [+ LUT].  Keep the LUT in LDS while a workgroup fits in 144 KiB.
+    const size_t mask_bytes = (((size_t)(1u << k_mux) * nw + 3) & ~size_t(3)) * 4;
+    const size_t lut_bytes = lut.size() * 4;
+    h->lut_in_lds = mask_bytes + lut_bytes + 64 <= 144 * 1024;
+    h->shmem = mask_bytes + (h->lut_in_lds ? lut_bytes : 0) + 64;
+    HIPCHK(h, configure_kernels((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
+    h->have_net = true;
+    return BSX_OK;
+}
+
+extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_words,
+                                     const uint32_t* any_nodes, uint32_t n_any,
+                                     const bsx_fixed* fixed, uint32_t n_fixed,
+                                     const bsx_fixed_var* fixed_var, uint32_t n_fixed_var,
+                                     const bsx_pert* sched, uint32_t n_sched,
+                                     const bsx_pert_var* pert_var, uint32_t n_pert_var) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net) return fail(h, BSX_ERR_STATE, "bsx_set_problem_space before bsx_set_network");
+    if (!origin_state_words) return fail(h, BSX_ERR_INVALID, "origin state is null");
+    if (n_pert_var > BSX_MAX_PERT_VARIATIONS) return fail(h, BSX_ERR_UNSUPPORTED, "more than BSX_MAX_PERT_VARIATIONS perturbation variations");
+    if (n_any > h->n_nodes) return fail(h, BSX_ERR_INVALID, "more 'any' nodes than nodes");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->have_space = false;
+    const uint32_t n = h->n_nodes, nw = h->net.nw;
+    DevSpace sp{};
+    for (uint32_t w = 0; w < h->w64; ++w) {
+        uint64_t word = origin_state_words[w];
+        if (w == h->w64 - 1 && (n & 63)) word &= (1ull << (n & 63)) - 1;
+        sp.origin[2 * w] = (uint32_t)word;
+        if (2 * w + 1 < (uint32_t)kMaxW32) sp.origin[2 * w + 1] = (uint32_t)(word >> 32);
+    }
+    std::vector<uint32_t> any(n_any);
+    bool identity = true;
+    for (uint32_t j = 0; j < n_any; ++j) {
+        if (any_nodes[j] >= n || (j && any_nodes[j] <= any_nodes[j - 1]))
+            return fail(h, BSX_ERR_INVALID, "'any' nodes must be ascending node indices");
+        any[j] = any_nodes[j];
+        identity = identity && any_nodes[j] == j;
+        sp.origin[any_nodes[j] >> 5] &= ~(1u << (any_nodes[j] & 31));   // digit decides
+    }
+    for (uint32_t j = 0; j < n_fixed; ++j) {
+        if (fixed[j].node >= n || fixed[j].value > 1) return fail(h, BSX_ERR_INVALID, "bad fixed node entry");
+        sp.fixmask[fixed[j].node >> 5] |= 1u << (fixed[j].node & 31);
+        if (fixed[j].value) sp.fixval[fixed[j].node >> 5] |= 1u << (fixed[j].node & 31);
+        else sp.fixval[fixed[j].node >> 5] &= ~(1u << (fixed[j].node & 31));
+    }
+    std::vector<uint32_t> fv, pv;
+    for (uint32_t j = 0; j < n_fixed_var; ++j) {
+        if (fixed_var[j].node >= n || fixed_var[j].range > 3) return fail(h, BSX_ERR_INVALID, "bad fixed-node variation");
+        fv.push_back(fixed_var[j].node); fv.push_back(fixed_var[j].range);
+    }
+    uint32_t tp_origin = 0;
+    for (uint32_t j = 0; j < n_sched; ++j) {
+        if (sched[j].node >= n || sched[j].value > 1 || sched[j].t == 0) return fail(h, BSX_ERR_INVALID, "bad perturbation entry");
+        tp_origin = std::max(tp_origin, sched[j].t);
+    }
+    for (uint32_t j = 0; j < n_pert_var; ++j) {
+        if (pert_var[j].node >= n || pert_var[j].range > 3 || pert_var[j].t == 0) return fail(h, BSX_ERR_INVALID, "bad perturbation variation");
+        pv.push_back(pert_var[j].t); pv.push_back(pert_var[j].node); pv.push_back(pert_var[j].range);
+    }
+    if ((uint64_t)(tp_origin + 1) * nw * 8 > (1ull << 30)) return fail(h, BSX_ERR_UNSUPPORTED, "perturbation schedule too long for the dense table");
+    std::vector<uint32_t> set((size_t)(tp_origin + 1) * nw, 0), clr((size_t)(tp_origin + 1) * nw, 0);
+    for (uint32_t j = 0; j < n_sched; ++j) {
+        const size_t at = (size_t)sched[j].t * nw + (sched[j].node >> 5);
+        const uint32_t m = 1u << (sched[j].node & 31);
+        if (sched[j].value) { set[at] |= m; clr[at] &= ~m; } else { clr[at] |= m; set[at] &= ~m; }
+    }
+    HIPCHK(h, h->d_any.upload(any));
+    HIPCHK(h, h->d_fv.upload(fv));
+    HIPCHK(h, h->d_pv.upload(pv));
+    HIPCHK(h, h->d_set.upload(set));
+    HIPCHK(h, h->d_clr.upload(clr));
+    sp.n_any = n_any;
+    sp.identity_any = identity ? 1 : 0;
+    sp.n_fv = n_fixed_var;
+    sp.n_pv = n_pert_var;
+    sp.tp_origin = tp_origin;
+    sp.any_nodes = h->d_any.p;
+    sp.fv = h->d_fv.p;
+    sp.pv = h->d_pv.p;
+    sp.sched_set = h->d_set.p;
+    sp.sched_clr = h->d_clr.p;
+    h->sp = sp;
+    h->have_space = true;
+    return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Launch {
+    dim3 grid;
+    uint32_t chunk;
+};
+
+Launch plan_persistent(const bsx_engine* h, uint64_t count) {
+    const uint32_t cus = (uint32_t)h->prop.multiProcessorCount;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(h->shmem, 1));
+    per_cu = std::max(1u, std::min(per_cu, 4u));
+    uint64_t blocks = (uint64_t)cus * per_cu;
+    const uint64_t need = (count + kBlock - 1) / kBlock;
+    blocks = std::max<uint64_t>(1, std::min(blocks, need));
+    const uint64_t waves = blocks * kWavesPerBlock;
+    uint64_t chunk = count / (waves * 8);
+    chunk = std::min<uint64_t>(4096, std::max<uint64_t>(64, chunk));
+    chunk = (chunk / 64) * 64;
+    return Launch{dim3((uint32_t)blocks), (uint32_t)chunk};
+}
+
+int check_index(bsx_handle h, const bsx_index* first) {
+    if (!first) return fail(h, BSX_ERR_INVALID, "first index is null");
+    const uint32_t n_any = h->sp.n_any;
+    for (uint32_t b = n_any; b < 64 * BSX_MAX_WORDS; ++b)
+        if ((first->init_digits[b >> 6] >> (b & 63)) & 1ull)
+            return fail(h, BSX_ERR_INVALID, "init_digits has bits at or above n_any");
+    return BSX_OK;
+}
+
+void set_first(DevSpace& sp, const bsx_index* first) {
+    for (int w = 0; w < 4; ++w) sp.first_digits[w] = first->init_digits[w];
+    sp.first_variant = first->variant;
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct KeyLess {
+    bool operator()(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) const { return a < b; }
+};
+
+}  // namespace
+
+extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                               uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
+                               uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
+    if (int rc = check_index(h, first)) return rc;
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_out = 0;
+    if (n_no_attractor) *n_no_attractor = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+    if (max_t != BSX_T_INF && max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
+
+    const Launch L = plan_persistent(h, count);
+    const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
+    const uint64_t log_cap = waves * kTableSlots + (1u << 16);
+    DevBuf<LogRec> d_log;
+    HIPCHK(h, d_log.alloc(log_cap));
+    DevBuf<ProblemRec32> d_pp;
+    if (per_problem) HIPCHK(h, d_pp.alloc(count));
+
+    AttractParams P{};
+    P.net = h->net;
+    P.sp = h->sp;
+    set_first(P.sp, first);
+    P.count = count;
+    P.chunk = L.chunk;
+    P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
+    P.max_t = max_t;
+    P.max_len = max_len;
+    P.ctr = h->d_ctr.p;
+    P.log = d_log.p;
+    P.log_cap = log_cap;
+    P.per_problem = per_problem ? d_pp.p : nullptr;
+
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    Counters ctr{};
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+
+    if (ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
+    const uint64_t n_log = ctr.log_cursor;
+    std::vector<LogRec> log(n_log);
+    if (n_log) HIPCHK(h, hipMemcpy(log.data(), d_log.p, n_log * sizeof(LogRec), hipMemcpyDeviceToHost));
+
+    // merge by key (attract.py:405-455 write_aggregated_attractors_to_db, exact integers)
+    std::map<std::vector<uint32_t>, bsx_attr_rec, KeyLess> merged;
+    const uint32_t nw = h->net.nw;
+    for (const LogRec& r : log) {
+        std::vector<uint32_t> key(r.key, r.key + nw);
+        auto it = merged.find(key);
+        if (it == merged.end()) {
+            bsx_attr_rec a{};
+            for (uint32_t w = 0; w < nw; ++w) a.key[w >> 1] |= (uint64_t)r.key[w] << (32 * (w & 1));
+            a.length = r.length;
+            it = merged.emplace(key, a).first;
+        }
+        bsx_attr_rec& a = it->second;
+        a.count += r.count;
+        a.sum_l += r.sum_l;
+        const uint64_t lo = a.sum_l2_lo + r.sum_l2;
+        if (lo < a.sum_l2_lo) ++a.sum_l2_hi;
+        a.sum_l2_lo = lo;
+    }
+    if (merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
+    uint32_t i = 0;
+    for (auto& kv : merged) table[i++] = kv.second;
+    *n_out = i;
+    if (n_no_attractor) *n_no_attractor = ctr.n_none;
+
+    if (per_problem) {
+        std::vector<ProblemRec32> pp(count);
+        HIPCHK(h, hipMemcpy(pp.data(), d_pp.p, count * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
+        for (uint64_t p = 0; p < count; ++p) {
+            bsx_problem_rec o{};
+            for (uint32_t w = 0; w < nw; ++w) o.key[w >> 1] |= (uint64_t)pp[p].key[w] << (32 * (w & 1));
+            o.length = pp[p].length; o.trajectory_l = pp[p].trajectory_l; o.found = pp[p].found;
+            per_problem[p] = o;
+        }
+    }
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = ctr.steps_ref;
+        stats->executed_steps = ctr.steps_exec;
+        stats->kernel_ms = ms;
+        stats->kernel_launches = 1;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    if (ctr.step_limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit without closing its cycle");
+    return BSX_OK;
+}
+
+extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                              const uint64_t* mask_words, const uint64_t* code_words, bsx_hit* hits,
+                              uint64_t cap, uint64_t* n_hits, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (!mask_words || !code_words || !n_hits || (cap && !hits)) return fail(h, BSX_ERR_INVALID, "null argument");
+    if (int rc = check_index(h, first)) return rc;
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_hits = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+
+    const Launch L = plan_persistent(h, count);
+    DevBuf<HitRec> d_hits;
+    HIPCHK(h, d_hits.alloc(std::min<uint64_t>(cap, count)));
+    TargetParams P{};
+    P.net = h->net;
+    P.sp = h->sp;
+    set_first(P.sp, first);
+    P.count = count;
+    P.chunk = L.chunk;
+    P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
+    P.max_t = max_t;
+    for (uint32_t w = 0; w < h->w64; ++w) {
+        P.tmask[2 * w] = (uint32_t)mask_words[w]; P.tcode[2 * w] = (uint32_t)code_words[w];
+        if (2 * w + 1 < (uint32_t)kMaxW32) { P.tmask[2 * w + 1] = (uint32_t)(mask_words[w] >> 32); P.tcode[2 * w + 1] = (uint32_t)(code_words[w] >> 32); }
+    }
+    P.ctr = h->d_ctr.p;
+    P.hits = d_hits.p;
+    P.hits_cap = std::min<uint64_t>(cap, count);
+
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    Counters ctr{};
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "more hits than the caller's capacity");
+    static_assert(sizeof(HitRec) == sizeof(bsx_hit), "hit layout");
+    if (ctr.log_cursor) HIPCHK(h, hipMemcpy(hits, d_hits.p, ctr.log_cursor * sizeof(HitRec), hipMemcpyDeviceToHost));
+    *n_hits = ctr.log_cursor;
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = ctr.steps_ref;
+        stats->executed_steps = ctr.steps_exec;
+        stats->kernel_ms = ms;
+        stats->kernel_launches = 1;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    if (ctr.step_limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit");
+    return BSX_OK;
+}
+
+static int run_sim_common(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                          const uint64_t* offsets, const uint64_t* t_len, const uint64_t* out_offsets,
+                          uint64_t traj_words, uint64_t* trajectories, uint64_t* final_states,
+                          uint64_t* digests, bsx_stats* stats) {
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+    if (max_t >= kStepLimit) return fail(h, BSX_ERR_UNSUPPORTED, "simulation length above the engine's step limit");
+    const uint32_t W = h->w64;
+    DevBuf<uint64_t> d_traj, d_final, d_dig, d_off, d_tlen, d_ooff;
+    if (trajectories) HIPCHK(h, d_traj.alloc(traj_words));
+    if (final_states) HIPCHK(h, d_final.alloc(count * W));
+    if (digests) HIPCHK(h, d_dig.alloc(count));
+    if (offsets) { HIPCHK(h, d_off.alloc(count)); HIPCHK(h, hipMemcpy(d_off.p, offsets, count * 8, hipMemcpyHostToDevice)); }
+    if (t_len) { HIPCHK(h, d_tlen.alloc(count)); HIPCHK(h, hipMemcpy(d_tlen.p, t_len, count * 8, hipMemcpyHostToDevice)); }
+    if (out_offsets) { HIPCHK(h, d_ooff.alloc(count)); HIPCHK(h, hipMemcpy(d_ooff.p, out_offsets, count * 8, hipMemcpyHostToDevice)); }
+
+    SimParams P{};
+    P.net = h->net;
+    P.sp = h->sp;
+    set_first(P.sp, first);
+    P.count = count;
+    P.max_t = max_t;
+    P.w64 = W;
+    P.offsets = offsets ? d_off.p : nullptr;
+    P.t_len = t_len ? d_tlen.p : nullptr;
+    P.out_offsets = out_offsets ? d_ooff.p : nullptr;
+    P.traj = trajectories ? d_traj.p : nullptr;
+    P.final_states = final_states ? d_final.p : nullptr;
+    P.digests = digests ? d_dig.p : nullptr;
+    P.ctr = h->d_ctr.p;
+
+    const uint32_t cus = (uint32_t)h->prop.multiProcessorCount;
+    const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 4, (count + kBlock - 1) / kBlock));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_simulate((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, dim3((uint32_t)blocks), h->shmem, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    Counters ctr{};
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (trajectories) HIPCHK(h, hipMemcpy(trajectories, d_traj.p, traj_words * 8, hipMemcpyDeviceToHost));
+    if (final_states) HIPCHK(h, hipMemcpy(final_states, d_final.p, count * W * 8, hipMemcpyDeviceToHost));
+    if (digests) HIPCHK(h, hipMemcpy(digests, d_dig.p, count * 8, hipMemcpyDeviceToHost));
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = ctr.steps_ref;
+        stats->executed_steps = ctr.steps_exec;
+        stats->kernel_ms = ms;
+        stats->kernel_launches = 1;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    return BSX_OK;
+}
+
+extern "C" int bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                                uint64_t* trajectories, uint64_t* final_states, uint64_t* digests,
+                                bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (int rc = check_index(h, first)) return rc;
+    if (max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
+    const uint64_t words = trajectories ? count * (max_t + 1) * h->w64 : 0;
+    return run_sim_common(h, first, count, max_t, nullptr, nullptr, nullptr, words, trajectories, final_states,
+                          digests, stats);
+}
+
+extern "C" int bsx_run_trajectories(bsx_handle h, const bsx_index* first, const uint64_t* offsets,
+                                    const uint64_t* t_len, uint64_t n, uint64_t* out,
+                                    const uint64_t* out_offsets, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (int rc = check_index(h, first)) return rc;
+    if (n && (!offsets || !t_len || !out || !out_offsets)) return fail(h, BSX_ERR_INVALID, "null argument");
+    uint64_t words = 0, tmax = 0;
+    for (uint64_t q = 0; q < n; ++q) {
+        words = std::max(words, out_offsets[q] + (t_len[q] + 1) * h->w64);
+        tmax = std::max(tmax, t_len[q]);
+    }
+    return run_sim_common(h, first, n, tmax, offsets, t_len, out_offsets, words, out, nullptr, nullptr, stats);
+}

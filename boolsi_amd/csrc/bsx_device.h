@@ -1,0 +1,126 @@
+// Shared host/device structures of the gfx950 engine (kernel parameters).  See DESIGN.md.
+#pragma once
+#include <stdint.h>
+
+namespace bsx {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;                 // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxW32 = 8;                  // 32-bit words per state (n <= 256)
+constexpr int kMaxMuxK = 6;                 // nodes with more predecessors take the "wide" path
+constexpr int kTableSlots = 64;             // per-wave LDS attractor table: one slot per lane
+constexpr uint32_t kStepLimit = 1u << 30;   // internal per-trajectory step limit (u32 counters)
+constexpr uint64_t kDigestSeed = 0xCBF29CE484222325ull;
+constexpr uint64_t kDigestPrime = 0x100000001B3ull;
+
+// Network tables in HBM (staged into LDS by each workgroup where they fit).
+struct DevNet {
+    uint32_t n_nodes;
+    uint32_t nw;            // 32-bit words per state
+    uint32_t k_mux;         // gathered predecessor slots (max degree over mux nodes, >= 1)
+    uint32_t n_chunks;      // 8-bit chunks of the state that feed the gather LUT = ceil(n/8)
+    uint32_t lut_words;     // n_chunks * 256 * k_mux * nw
+    uint32_t n_wide;
+    const uint32_t* lut;    // [chunk][byte value][slot j][word w]: bits i with pred_j(i) in chunk and set in value
+    const uint32_t* masks;  // [1 << k_mux][nw]: bit i = TT_i(idx)   (0 for wide nodes)
+    const uint32_t* wide_desc;   // per wide node: node, k, first pred, first tt word (u32)
+    const uint32_t* wide_preds;
+    const uint32_t* wide_tt;     // 32-bit words of the wide truth tables
+};
+
+// Problem space (enumeration) tables.
+struct DevSpace {
+    uint32_t origin[kMaxW32];
+    uint32_t fixmask[kMaxW32];      // origin fixed nodes
+    uint32_t fixval[kMaxW32];
+    uint32_t n_any;
+    uint32_t identity_any;          // any-nodes are exactly nodes 0..n_any-1: digits deposit = OR
+    uint32_t n_fv;
+    uint32_t n_pv;
+    uint32_t tp_origin;             // last origin perturbation time (0 = none)
+    uint32_t pad;
+    const uint32_t* any_nodes;      // [n_any]
+    const uint32_t* fv;             // [n_fv][2]  node, range
+    const uint32_t* pv;             // [n_pv][3]  t, node, range
+    const uint32_t* sched_set;      // [tp_origin + 1][nw]  bits forced to 1 at time t
+    const uint32_t* sched_clr;      // [tp_origin + 1][nw]  bits forced to 0 at time t
+    uint64_t first_digits[4];
+    uint64_t first_variant;
+};
+
+// One record of the device-side attractor log (merged on the host).
+struct LogRec {
+    uint32_t key[kMaxW32];
+    uint32_t length;
+    uint32_t count;
+    uint64_t sum_l;
+    uint64_t sum_l2;
+};
+static_assert(sizeof(LogRec) == 56, "LogRec layout");
+
+struct ProblemRec32 {           // per-problem output, device layout
+    uint32_t key[kMaxW32];
+    uint32_t length;
+    uint32_t trajectory_l;
+    uint32_t found;
+    uint32_t pad;
+};
+
+struct Counters {               // zeroed before every launch
+    unsigned long long cursor;          // next chunk of problems
+    unsigned long long steps_ref;       // reference-equivalent steps
+    unsigned long long steps_exec;      // executed network updates
+    unsigned long long n_none;          // problems without attractor
+    unsigned long long log_cursor;      // records appended to the log / hits
+    unsigned int log_overflow;
+    unsigned int step_limit_hits;
+};
+
+struct AttractParams {
+    DevNet net;
+    DevSpace sp;
+    uint64_t count;
+    uint32_t chunk;             // problems per dequeue
+    uint32_t cap_rel_inf;       // 1: max_t is infinite
+    uint64_t max_t;             // absolute cap (valid when !cap_rel_inf)
+    uint64_t max_len;           // attractor length cap (UINT64_MAX = none)
+    Counters* ctr;
+    LogRec* log;
+    uint64_t log_cap;
+    ProblemRec32* per_problem;  // nullable
+};
+
+struct HitRec { uint64_t offset; uint64_t t; };
+
+struct TargetParams {
+    DevNet net;
+    DevSpace sp;
+    uint64_t count;
+    uint32_t chunk;
+    uint32_t cap_rel_inf;
+    uint64_t max_t;
+    uint32_t tmask[kMaxW32];
+    uint32_t tcode[kMaxW32];
+    Counters* ctr;
+    HitRec* hits;
+    uint64_t hits_cap;
+};
+
+struct SimParams {
+    DevNet net;
+    DevSpace sp;
+    uint64_t count;
+    uint64_t max_t;             // used when t_len == nullptr
+    uint32_t w64;               // uint64 words per state in the outputs
+    uint32_t pad;
+    const uint64_t* offsets;    // nullable: problem q = first + offsets[q]  (else first + q)
+    const uint64_t* t_len;      // nullable: per-problem length
+    const uint64_t* out_offsets;// nullable: word offset of problem q's trajectory
+    uint64_t* traj;             // nullable
+    uint64_t* final_states;     // nullable
+    uint64_t* digests;          // nullable
+    Counters* ctr;
+};
+
+}  // namespace bsx

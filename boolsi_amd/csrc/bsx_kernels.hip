@@ -1,0 +1,761 @@
+// gfx950 kernels of the Boolean-network state-update engine.
+//
+// Work decomposition: one LANE = one trajectory, state packed in NW 32-bit registers.
+// A step gathers every node's predecessor bits with byte-indexed LUTs staged in LDS (one lookup per
+// 8 state bits yields the gathered words of all K predecessor slots at once) and evaluates all
+// truth tables of the network together as a K-level v_bfi mux tree over bit-packed table masks.
+// Trajectories end at data-dependent times, so waves are persistent: a lane whose problem is
+// resolved immediately takes the next problem index of its wave's chunk (wave-level dequeue with
+// __ballot/__popcll), keeping all 64 lanes busy.  Cycle detection is Brent's algorithm per lane;
+// the minimum state code of the cycle (the attractor key) is tracked during the detection lap, the
+// trajectory length mu comes from a lagged two-pointer pass.  Results are aggregated in registers
+// (per-lane run of equal keys), then in a per-wave table (one slot per lane, matched with ballots),
+// then appended to a log in HBM.
+//
+// Replaces (reference file:line): apply_update_rules model.py:16-28, fixed nodes 31-49, simulate_step
+// 52-73, warm-up 76-128, detection loop 152-236, solvers attract.py:262-302 / target.py:109-133 /
+// simulate.py:97-131, store_attractor attract.py:374-402, problem enumeration batching.py:160-282.
+#include <hip/hip_runtime.h>
+#include "bsx_device.h"
+
+namespace bsx {
+
+__device__ __forceinline__ uint32_t bfi(uint32_t sel, uint32_t a, uint32_t b) {
+    return (a & sel) | (b & ~sel);      // v_bfi_b32
+}
+
+template <int NW>
+__device__ __forceinline__ bool eq_words(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) d |= a[w] ^ b[w];
+    return d == 0;
+}
+
+// a < b as big integers, word NW-1 most significant (state code order, model.py:131-149)
+template <int NW>
+__device__ __forceinline__ bool lt_words(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
+    bool lt = false, eq = true;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) {
+        lt = lt || (eq && a[w] < b[w]);
+        eq = eq && (a[w] == b[w]);
+    }
+    return lt;
+}
+
+template <int NW>
+__device__ __forceinline__ void copy_words(uint32_t (&dst)[NW], const uint32_t (&src)[NW]) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dst[w] = src[w];
+}
+
+// Bit access by (wave-uniform or per-lane) node number.  Written as mask arithmetic over ALL words so
+// that the state arrays keep static indices and stay in registers (a select over array elements gets
+// turned into a dynamically indexed access by the compiler, which would push the arrays to scratch).
+template <int NW>
+__device__ __forceinline__ uint32_t get_bit(const uint32_t (&s)[NW], uint32_t node) {
+    const uint32_t m = 1u << (node & 31);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc |= s[w] & (((node >> 5) == (uint32_t)w) ? m : 0u);
+    return acc ? 1u : 0u;
+}
+
+template <int NW>
+__device__ __forceinline__ void put_bit(uint32_t (&s)[NW], uint32_t node, uint32_t v) {
+    const uint32_t m = 1u << (node & 31);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t mw = ((node >> 5) == (uint32_t)w) ? m : 0u;
+        s[w] = (s[w] & ~mw) | (v ? mw : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Network tables as seen by a workgroup: LUT and masks either in LDS or (large networks) in HBM/L2.
+template <int NW, int K>
+struct NetView {
+    const uint32_t* lut;     // LDS or global
+    const uint32_t* masks;   // LDS
+    uint32_t n_chunks;
+    uint32_t n_wide;
+    const uint32_t* wide_desc;
+    const uint32_t* wide_preds;
+    const uint32_t* wide_tt;
+};
+
+// Load one LUT entry (N consecutive words) with the widest loads its size allows.
+template <int N>
+__device__ __forceinline__ void load_entry(const uint32_t* e, uint32_t (&dst)[N]) {
+    if constexpr (N % 4 == 0) {
+        const uint4* p = reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const uint4 v = p[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else if constexpr (N % 2 == 0) {
+        const uint2* p = reinterpret_cast<const uint2*>(__builtin_assume_aligned(e, 8));
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const uint2 v = p[i];
+            dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) dst[i] = e[i];
+    }
+}
+
+// One synchronous update of all nodes (model.py:16-28) + fixed nodes as constants (model.py:31-49).
+template <int NW, int K>
+__device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_t (&s)[NW],
+                                         const uint32_t (&fm)[NW], const uint32_t (&fv)[NW],
+                                         uint32_t (&out)[NW]) {
+    uint32_t g[K][NW];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) g[j][w] = 0;
+
+    // gather: one LUT entry per 8 state bits
+#pragma unroll
+    for (int ch = 0; ch < NW * 4; ++ch) {
+        if ((uint32_t)ch < nv.n_chunks) {
+            const uint32_t v = (s[ch >> 2] >> ((ch & 3) * 8)) & 0xFFu;
+            uint32_t e[K * NW];
+            load_entry<K * NW>(nv.lut + ((uint32_t)(ch << 8) + v) * (K * NW), e);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) g[j][w] |= e[j * NW + w];
+        }
+    }
+
+    // mux tree over the bit-packed truth-table masks: level j selects on predecessor slot j
+    uint32_t r[1 << (K - 1)][NW];
+#pragma unroll
+    for (int i = 0; i < (1 << (K - 1)); ++i)
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            r[i][w] = bfi(g[0][w], nv.masks[(2 * i + 1) * NW + w], nv.masks[(2 * i) * NW + w]);
+#pragma unroll
+    for (int j = 1; j < K; ++j)
+#pragma unroll
+        for (int i = 0; i < (1 << (K - 1 - j)); ++i)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) r[i][w] = bfi(g[j][w], r[2 * i + 1][w], r[2 * i][w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) out[w] = r[0][w];
+
+    // nodes with more than kMaxMuxK predecessors: explicit table lookup
+    for (uint32_t q = 0; q < nv.n_wide; ++q) {
+        const uint32_t node = nv.wide_desc[4 * q], k = nv.wide_desc[4 * q + 1];
+        const uint32_t* preds = nv.wide_preds + nv.wide_desc[4 * q + 2];
+        const uint32_t* tt = nv.wide_tt + nv.wide_desc[4 * q + 3];
+        uint32_t idx = 0;
+        for (uint32_t j = 0; j < k; ++j) idx |= get_bit<NW>(s, preds[j]) << j;
+        const uint32_t bit = (tt[idx >> 5] >> (idx & 31)) & 1u;
+        put_bit<NW>(out, node, bit);
+    }
+
+#pragma unroll
+    for (int w = 0; w < NW; ++w) out[w] = (out[w] & ~fm[w]) | fv[w];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Problem enumeration (batching.py:160-229): offset p within the run -> initial state, fixed-node
+// masks, perturbation-variation digits, last perturbation time.
+template <int NW>
+struct Problem {
+    uint32_t s[NW];
+    uint32_t fm[NW];
+    uint32_t fv[NW];
+    uint64_t pv_digits;   // 2 bits per perturbation variation
+    uint32_t tp;
+};
+
+__device__ __forceinline__ int digit_state(uint32_t range, uint32_t digit) {
+    // batching.py:171-175; -1 = absent
+    if (range == 0) return digit ? 0 : -1;
+    if (range == 1) return digit ? 1 : -1;
+    if (range == 2) return digit ? 1 : 0;
+    return digit == 0 ? -1 : (digit == 1 ? 0 : 1);
+}
+
+template <int NW>
+__device__ __forceinline__ void init_problem(const DevSpace& sp, uint64_t p, Problem<NW>& pr) {
+    // digits = first_digits + p; what spills over bit n_any goes to the variant number
+    uint64_t d[5];
+    unsigned long long carry = p;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long a = sp.first_digits[w];
+        const unsigned long long sum = a + carry;
+        carry = (sum < a) ? 1ull : 0ull;
+        d[w] = sum;
+    }
+    d[4] = carry;
+    const uint32_t sw = sp.n_any >> 6, sb = sp.n_any & 63;
+    uint64_t lo = d[0], hi = d[1];   // words sw, sw+1
+#pragma unroll
+    for (int w = 1; w < 5; ++w) {
+        lo = (sw == (uint32_t)w) ? d[w] : lo;
+        hi = (sw + 1 == (uint32_t)w) ? d[w] : hi;
+    }
+    if (sw >= 4) hi = 0;
+    uint64_t over = sb ? ((lo >> sb) | (hi << (64 - sb))) : lo;
+    uint64_t variant = sp.first_variant + over;
+    // keep only the n_any digits
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if ((uint32_t)w > sw) d[w] = 0;
+        else if ((uint32_t)w == sw) d[w] = sb ? (d[w] & ((1ull << sb) - 1)) : 0;
+    }
+
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        pr.s[w] = sp.origin[w];
+        pr.fm[w] = sp.fixmask[w];
+        pr.fv[w] = sp.fixval[w];
+    }
+    if (sp.identity_any) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint64_t word = d[w >> 1];
+            pr.s[w] |= (uint32_t)((w & 1) ? (word >> 32) : word);
+        }
+    } else {
+        uint64_t sh[4] = {d[0], d[1], d[2], d[3]};
+        for (uint32_t j = 0; j < sp.n_any; ++j) {
+            put_bit<NW>(pr.s, sp.any_nodes[j], (uint32_t)(sh[0] & 1));
+            sh[0] = (sh[0] >> 1) | (sh[1] << 63);
+            sh[1] = (sh[1] >> 1) | (sh[2] << 63);
+            sh[2] = (sh[2] >> 1) | (sh[3] << 63);
+            sh[3] >>= 1;
+        }
+    }
+    for (uint32_t j = 0; j < sp.n_fv; ++j) {
+        const uint32_t node = sp.fv[2 * j], range = sp.fv[2 * j + 1];
+        uint32_t digit;
+        if (range == 3) { digit = (uint32_t)(variant % 3); variant /= 3; }
+        else { digit = (uint32_t)(variant & 1); variant >>= 1; }
+        const int st = digit_state(range, digit);
+        if (st >= 0) { put_bit<NW>(pr.fm, node, 1); put_bit<NW>(pr.fv, node, (uint32_t)st); }
+    }
+    pr.pv_digits = 0;
+    pr.tp = sp.tp_origin;
+    for (uint32_t j = 0; j < sp.n_pv; ++j) {
+        const uint32_t t = sp.pv[3 * j], range = sp.pv[3 * j + 2];
+        uint32_t digit;
+        if (range == 3) { digit = (uint32_t)(variant % 3); variant /= 3; }
+        else { digit = (uint32_t)(variant & 1); variant >>= 1; }
+        pr.pv_digits |= (uint64_t)digit << (2 * j);
+        if (digit_state(range, digit) >= 0 && t > pr.tp) pr.tp = t;     // model.py:125
+    }
+}
+
+// Perturbation override after the rules at time t (model.py:68-71): origin schedule, then the
+// problem's variation entries (which win over an origin entry of the same (t, node), batching.py:198-207).
+template <int NW>
+__device__ __forceinline__ void apply_perturbations(const DevSpace& sp, uint32_t t, uint64_t pv_digits,
+                                                    uint32_t (&s)[NW]) {
+    if (t <= sp.tp_origin) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            s[w] = (s[w] & ~sp.sched_clr[t * NW + w]) | sp.sched_set[t * NW + w];
+    }
+    for (uint32_t j = 0; j < sp.n_pv; ++j) {
+        if (sp.pv[3 * j] == t) {
+            const int st = digit_state(sp.pv[3 * j + 2], (uint32_t)(pv_digits >> (2 * j)) & 3u);
+            if (st >= 0) put_bit<NW>(s, sp.pv[3 * j + 1], (uint32_t)st);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workgroup prologue: stage LUT + masks into LDS.
+template <int NW, int K, bool LDS_LUT>
+__device__ __forceinline__ NetView<NW, K> stage_network(const DevNet& net, uint32_t* smem, uint32_t*& smem_free) {
+    NetView<NW, K> nv;
+    uint32_t* p = smem;
+    uint32_t* smasks = p;
+    const uint32_t n_masks = (1u << K) * NW;
+    for (uint32_t i = threadIdx.x; i < n_masks; i += blockDim.x) smasks[i] = net.masks[i];
+    p += (n_masks + 3u) & ~3u;
+    if (LDS_LUT) {
+        uint32_t* slut = p;
+        const uint4* src = reinterpret_cast<const uint4*>(net.lut);
+        uint4* dst = reinterpret_cast<uint4*>(slut);
+        const uint32_t n4 = net.lut_words >> 2;     // lut_words is a multiple of 4 (256 entries per chunk)
+        for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+        p += net.lut_words;
+        nv.lut = slut;
+    } else {
+        nv.lut = net.lut;
+    }
+    __syncthreads();
+    nv.masks = smasks;
+    nv.n_chunks = net.n_chunks;
+    nv.n_wide = net.n_wide;
+    nv.wide_desc = net.wide_desc;
+    nv.wide_preds = net.wide_preds;
+    nv.wide_tt = net.wide_tt;
+    smem_free = p;
+    return nv;
+}
+
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-wave attractor table: slot i lives in lane i's registers, so a probe is one compare per lane
+// and two ballots (attract.py:374-402 store_attractor, integer sums instead of Chan's float update).
+template <int NW>
+struct TableSlot {
+    uint32_t key[NW];
+    uint32_t length;
+    uint32_t count;
+    uint64_t sum_l;
+    uint64_t sum_l2;
+};
+
+template <int NW>
+__device__ __forceinline__ void log_append(const AttractParams& P, const uint32_t (&key)[NW], uint32_t length,
+                                           uint32_t count, uint64_t sl, uint64_t sl2) {
+    const unsigned long long at = atomicAdd(&P.ctr->log_cursor, 1ull);
+    if (at < P.log_cap) {
+        LogRec r;
+#pragma unroll
+        for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r.key[w] = key[w];
+        r.length = length; r.count = count; r.sum_l = sl; r.sum_l2 = sl2;
+        P.log[at] = r;
+    } else {
+        atomicOr(&P.ctr->log_overflow, 1u);
+    }
+}
+
+// Merge the records of all lanes flagged in `want` into the wave's table (wave-uniform loop).
+template <int NW>
+__device__ __forceinline__ void table_merge(const AttractParams& P, TableSlot<NW>& slot, int lane, bool want,
+                                            const uint32_t (&key)[NW], uint32_t length, uint32_t count,
+                                            uint64_t sl, uint64_t sl2) {
+    uint64_t todo = __ballot(want);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = __builtin_amdgcn_readlane(key[w], src);
+        const uint32_t len = __builtin_amdgcn_readlane(length, src);
+        const uint32_t cnt = __builtin_amdgcn_readlane(count, src);
+        const uint64_t a = bcast64(sl, src), b = bcast64(sl2, src);
+        // a slot whose 64-bit sum of squares is nearly full stops matching; the record then opens
+        // another slot (or goes to the log) and the host merge adds them up in 128 bits
+        const bool same = slot.count != 0 && eq_words<NW>(slot.key, k) && slot.sum_l2 < (1ull << 62);
+        const uint64_t hit = __ballot(same);
+        const uint64_t empty = __ballot(slot.count == 0);
+        if (hit) {
+            if (lane == __builtin_ctzll(hit)) { slot.count += cnt; slot.sum_l += a; slot.sum_l2 += b; }
+        } else if (empty) {
+            if (lane == __builtin_ctzll(empty)) {
+                copy_words<NW>(slot.key, k);
+                slot.length = len; slot.count = cnt; slot.sum_l = a; slot.sum_l2 = b;
+            }
+        } else if (lane == 0) {
+            log_append<NW>(P, k, len, cnt, a, b);    // all 64 slots taken: straight to the HBM log
+        }
+    }
+}
+
+enum Phase : uint32_t { PH_IDLE = 0, PH_WARM = 1, PH_BRENT = 2, PH_ADVANCE = 3, PH_MU = 4 };
+
+// Wave-level dequeue of problem offsets.  Returns false when the wave is done.
+struct WaveQueue {
+    uint64_t next, end;
+    bool more;
+};
+
+__device__ __forceinline__ uint64_t grab_chunk(unsigned long long* cursor, uint32_t chunk, int lane) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)chunk);
+    return bcast64(base, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// attract: attract.py:262-302 semantics (S5-S7, S9, S10) for problems [first, first + count).
+template <int NW, int K, bool LDS_LUT>
+__global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const int lane = threadIdx.x & 63;
+    TableSlot<NW> slot;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) slot.key[w] = 0;
+    slot.length = 0; slot.count = 0; slot.sum_l = 0; slot.sum_l2 = 0;
+
+    uint32_t A[NW], B[NW], C[NW], D[NW], fm[NW], fv[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { A[w] = B[w] = C[w] = D[w] = 0; fm[w] = fv[w] = 0; }
+    uint32_t phase = PH_IDLE, t = 0, tp = 0, lam = 0, power = 1, cnt = 0, sub = 0;
+    uint32_t brent_limit = 0, cap_rel = 0;
+    uint64_t pv_digits = 0, my_p = 0;
+
+    uint32_t ck[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) ck[w] = 0;
+    uint32_t clen = 0, ccnt = 0;
+    uint64_t csl = 0, csl2 = 0;
+
+    uint64_t steps_ref = 0, steps_exec = 0;
+    uint32_t n_none = 0, limit_hits = 0;
+
+    WaveQueue q{0, 0, true};
+
+    for (;;) {
+        // ---- refill idle lanes with the next problems of the wave's chunk
+        const uint64_t idle = __ballot(phase == PH_IDLE);
+        if (idle) {
+            if (q.next == q.end && q.more) {
+                const uint64_t base = grab_chunk(&P.ctr->cursor, P.chunk, lane);
+                if (base >= P.count) q.more = false;
+                else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
+            }
+            const uint64_t avail = q.end - q.next;
+            if (avail) {
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                if (phase == PH_IDLE && rank < avail) {
+                    Problem<NW> pr;
+                    my_p = q.next + rank;
+                    init_problem<NW>(P.sp, my_p, pr);
+                    copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
+                    pv_digits = pr.pv_digits; tp = pr.tp; t = 0;
+                    // found iff mu + lambda <= max_t - T_p (S7); Brent needs at most 3x that many steps
+                    if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
+                    else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
+                    if (tp > 0) phase = PH_WARM;
+                    else {
+                        phase = PH_BRENT; lam = 0; power = 1;
+                        copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+                    }
+                }
+                const uint64_t taken = (uint64_t)__popcll(idle) < avail ? (uint64_t)__popcll(idle) : avail;
+                q.next += taken;
+            } else if (!q.more && idle == ~0ull) {
+                break;
+            }
+        }
+
+        // ---- one network update per lane per iteration
+        const bool step_b = (phase == PH_MU) && sub;
+        uint32_t cur[NW], nxt[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) cur[w] = step_b ? B[w] : A[w];
+        net_step<NW, K>(nv, cur, fm, fv, nxt);
+
+        bool finished = false, found = false;
+        uint32_t mu = 0;
+
+        if (phase == PH_WARM) {
+            ++t; ++steps_exec;
+            apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
+            copy_words<NW>(A, nxt);
+            if (t == tp) {
+                phase = PH_BRENT; lam = 0; power = 1; t = 0;
+                copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+            }
+        } else if (phase == PH_BRENT) {
+            ++t; ++lam; ++steps_exec;
+            copy_words<NW>(A, nxt);
+            if (eq_words<NW>(A, B)) {
+                // cycle closed: lam = attractor length, C = min code seen since the tortoise moved = key
+                if (lam > cap_rel) finished = true;          // lambda alone exceeds max_t - T_p: not found
+                else { phase = PH_ADVANCE; cnt = 0; copy_words<NW>(A, D); copy_words<NW>(B, D); }
+            } else {
+                if (lt_words<NW>(A, C)) copy_words<NW>(C, A);
+                if (lam == power) { copy_words<NW>(B, A); copy_words<NW>(C, A); power <<= 1; lam = 0; }
+                if (t >= brent_limit) {
+                    finished = true;
+                    if (cap_rel == 0xFFFFFFFFu) ++limit_hits;
+                }
+            }
+        } else if (phase == PH_ADVANCE) {
+            ++steps_exec; ++cnt;
+            copy_words<NW>(A, nxt);
+            if (cnt == lam) { phase = PH_MU; cnt = 0; sub = 0; }
+        } else if (phase == PH_MU) {
+            if (!sub) {
+                if (eq_words<NW>(A, B)) { finished = true; found = true; mu = cnt; }
+                else if (cnt + lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { finished = true; }   // mu + lam > cap
+                else { copy_words<NW>(A, nxt); sub = 1; ++steps_exec; }
+            } else {
+                copy_words<NW>(B, nxt); sub = 0; ++cnt; ++steps_exec;
+            }
+        }
+
+        // ---- resolved problems: statistics, per-problem record, aggregation
+        bool flush = false;
+        uint32_t fk[NW], flen = 0, fcnt = 0;
+        uint64_t fsl = 0, fsl2 = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) fk[w] = 0;
+        if (finished) {
+            phase = PH_IDLE;
+            const uint64_t traj_l = (uint64_t)tp + mu;
+            // reference loop stops at T_p + mu + lambda when found, at max_t otherwise (model.py:201)
+            steps_ref += found ? traj_l + lam : (P.cap_rel_inf ? 0ull : P.max_t);
+            const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
+            if (P.per_problem) {
+                ProblemRec32 r;
+#pragma unroll
+                for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
+                if (keep) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) r.key[w] = C[w];
+                }
+                r.length = keep ? lam : 0; r.trajectory_l = keep ? (uint32_t)traj_l : 0; r.found = keep; r.pad = 0;
+                P.per_problem[my_p] = r;
+            }
+            if (!keep) ++n_none;
+            else if (ccnt && eq_words<NW>(ck, C) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += traj_l * traj_l; }
+            else {
+                if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
+                copy_words<NW>(ck, C); clen = lam; ccnt = 1; csl = traj_l; csl2 = traj_l * traj_l;
+            }
+        }
+        if (__ballot(flush)) table_merge<NW>(P, slot, lane, flush, fk, flen, fcnt, fsl, fsl2);
+    }
+
+    // ---- epilogue: lane caches -> wave table -> HBM log; counters
+    table_merge<NW>(P, slot, lane, ccnt != 0, ck, clen, ccnt, csl, csl2);
+    if (slot.count) log_append<NW>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
+    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_ref);
+    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps_exec);
+    if (n_none) atomicAdd(&P.ctr->n_none, (unsigned long long)n_none);
+    if (limit_hits) atomicAdd(&P.ctr->step_limit_hits, limit_hits);
+}
+
+template <int NW>
+__device__ __forceinline__ bool target_hit(const uint32_t (&s)[NW], const uint32_t (&tm)[NW], const uint32_t (&tc)[NW]) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) d |= (s[w] & tm[w]) ^ tc[w];
+    return d == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// target: stop at the first t >= T_p with (state & mask) == code; a trajectory that closes its cycle
+// (or hits max_t) first reaches nothing (target.py:109-133 over model.py:152-236, S12).
+template <int NW, int K, bool LDS_LUT>
+__global__ __launch_bounds__(kBlock) void k_target(const TargetParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const int lane = threadIdx.x & 63;
+
+    uint32_t A[NW], B[NW], fm[NW], fv[NW], tm[NW], tc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { A[w] = B[w] = fm[w] = fv[w] = 0; tm[w] = P.tmask[w]; tc[w] = P.tcode[w]; }
+    uint32_t phase = PH_IDLE, t = 0, tp = 0, lam = 0, power = 1, t_cap = 0;
+    uint64_t pv_digits = 0, my_p = 0;
+    uint64_t steps_ref = 0, steps_exec = 0;
+    uint32_t limit_hits = 0;
+    WaveQueue q{0, 0, true};
+
+    for (;;) {
+        const uint64_t idle = __ballot(phase == PH_IDLE);
+        if (idle) {
+            if (q.next == q.end && q.more) {
+                const uint64_t base = grab_chunk(&P.ctr->cursor, P.chunk, lane);
+                if (base >= P.count) q.more = false;
+                else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
+            }
+            const uint64_t avail = q.end - q.next;
+            if (avail) {
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                if (phase == PH_IDLE && rank < avail) {
+                    Problem<NW> pr;
+                    my_p = q.next + rank;
+                    init_problem<NW>(P.sp, my_p, pr);
+                    copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
+                    pv_digits = pr.pv_digits; tp = pr.tp; t = 0;
+                    t_cap = (P.cap_rel_inf || P.max_t >= kStepLimit) ? kStepLimit : (uint32_t)P.max_t;
+                    phase = tp > 0 ? PH_WARM : PH_BRENT;
+                    if (tp == 0) { lam = 0; power = 1; copy_words<NW>(B, A); }
+                }
+                const uint64_t taken = (uint64_t)__popcll(idle) < avail ? (uint64_t)__popcll(idle) : avail;
+                q.next += taken;
+            } else if (!q.more && idle == ~0ull) {
+                break;
+            }
+        }
+
+        // target check on the current state (covers s(T_p), model.py:200)
+        bool finished = false, reached = false;
+        if (phase == PH_BRENT) {
+            if (target_hit<NW>(A, tm, tc)) { finished = true; reached = true; }
+            else if (t >= t_cap) { finished = true; if (t_cap == kStepLimit) ++limit_hits; }
+        }
+        uint32_t nxt[NW];
+        net_step<NW, K>(nv, A, fm, fv, nxt);
+        if (!finished) {
+            if (phase == PH_WARM) {
+                ++t; ++steps_exec;
+                apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
+                copy_words<NW>(A, nxt);
+                if (t == tp) { phase = PH_BRENT; lam = 0; power = 1; copy_words<NW>(B, A); }
+            } else if (phase == PH_BRENT) {
+                ++t; ++lam; ++steps_exec;
+                copy_words<NW>(A, nxt);
+                if (eq_words<NW>(A, B)) finished = true;      // cycle closed, every state has been checked
+                else if (lam == power) { copy_words<NW>(B, A); power <<= 1; lam = 0; }
+            }
+        }
+        if (finished) {
+            phase = PH_IDLE;
+            steps_ref += t;
+            if (reached) {
+                const unsigned long long at = atomicAdd(&P.ctr->log_cursor, 1ull);
+                if (at < P.hits_cap) { P.hits[at].offset = my_p; P.hits[at].t = t; }
+                else atomicOr(&P.ctr->log_overflow, 1u);
+            }
+        }
+    }
+    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_ref);
+    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps_exec);
+    if (limit_hits) atomicAdd(&P.ctr->step_limit_hits, limit_hits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// simulate: s(0..T) by plain stepping (simulate.py:97-131 == S11); sinks: trajectory, final state, digest.
+template <int NW, int K, bool LDS_LUT>
+__global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t steps = 0;
+    for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < P.count; qi += stride) {
+        const uint64_t p = P.offsets ? P.offsets[qi] : qi;
+        const uint64_t T = P.t_len ? P.t_len[qi] : P.max_t;
+        Problem<NW> pr;
+        init_problem<NW>(P.sp, p, pr);
+        uint32_t s[NW];
+        copy_words<NW>(s, pr.s);
+        uint64_t* out = P.traj ? P.traj + (P.out_offsets ? P.out_offsets[qi] : qi * (P.max_t + 1) * P.w64) : nullptr;
+        uint64_t dg = kDigestSeed;
+        for (uint64_t t = 0;; ++t) {
+#pragma unroll
+            for (int w = 0; w < (NW + 1) / 2; ++w) {
+                uint64_t word = s[2 * w];
+                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                if ((uint32_t)w < P.w64) {
+                    if (out) out[t * P.w64 + w] = word;
+                    dg = (dg ^ word) * kDigestPrime;
+                }
+            }
+            if (t == T) break;
+            uint32_t nxt[NW];
+            net_step<NW, K>(nv, s, pr.fm, pr.fv, nxt);
+            if (t + 1 <= pr.tp) apply_perturbations<NW>(P.sp, (uint32_t)(t + 1), pr.pv_digits, nxt);
+            copy_words<NW>(s, nxt);
+            ++steps;
+        }
+        if (P.final_states) {
+#pragma unroll
+            for (int w = 0; w < (NW + 1) / 2; ++w) {
+                uint64_t word = s[2 * w];
+                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                if ((uint32_t)w < P.w64) P.final_states[qi * P.w64 + w] = word;
+            }
+        }
+        if (P.digests) P.digests[qi] = dg;
+    }
+    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps);
+    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch dispatch over (NW, K, LDS_LUT).  NW in {1,2,4,8}; K in 1..6.
+template <int NW, int K>
+static hipError_t launch_attract_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_attract<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
+    return hipGetLastError();
+}
+template <int NW, int K>
+static hipError_t launch_target_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
+    if (lds) hipLaunchKernelGGL((k_target<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_target<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
+    return hipGetLastError();
+}
+template <int NW, int K>
+static hipError_t launch_simulate_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
+    if (lds) hipLaunchKernelGGL((k_simulate<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_simulate<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
+    return hipGetLastError();
+}
+
+#define BSX_DISPATCH_K(FN, NWV)                                                         \
+    switch (k) {                                                                        \
+        case 1: return FN<NWV, 1>(lds, grid, shmem, st, P);                             \
+        case 2: return FN<NWV, 2>(lds, grid, shmem, st, P);                             \
+        case 3: return FN<NWV, 3>(lds, grid, shmem, st, P);                             \
+        case 4: return FN<NWV, 4>(lds, grid, shmem, st, P);                             \
+        case 5: return FN<NWV, 5>(lds, grid, shmem, st, P);                             \
+        case 6: return FN<NWV, 6>(lds, grid, shmem, st, P);                             \
+        default: return hipErrorInvalidValue;                                           \
+    }
+
+#define BSX_DISPATCH(FN)                                                                \
+    switch (nw) {                                                                       \
+        case 1: BSX_DISPATCH_K(FN, 1)                                                   \
+        case 2: BSX_DISPATCH_K(FN, 2)                                                   \
+        case 4: BSX_DISPATCH_K(FN, 4)                                                   \
+        case 8: BSX_DISPATCH_K(FN, 8)                                                   \
+        default: return hipErrorInvalidValue;                                           \
+    }
+
+hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    BSX_DISPATCH(launch_attract_nk)
+}
+hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
+    BSX_DISPATCH(launch_target_nk)
+}
+hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
+    BSX_DISPATCH(launch_simulate_nk)
+}
+
+template <int NW, int K>
+static hipError_t configure_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
+    const int bytes = (int)shmem;
+    hipError_t e;
+    if (lds) {
+        e = hipFuncSetAttribute((const void*)k_attract<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_target<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_simulate<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_attract<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_target<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_simulate<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
+    return e;
+}
+
+// Allow the instantiation used by a network to take `shmem` bytes of dynamic LDS (above 64 KiB this
+// must be requested explicitly).
+hipError_t configure_kernels(int nw, int k, bool lds, size_t shmem) {
+    const dim3 grid(1);
+    const hipStream_t st = nullptr;
+    const int P = 0;
+    BSX_DISPATCH(configure_nk)
+}
+
+}  // namespace bsx

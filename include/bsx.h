@@ -1,0 +1,170 @@
+/*
+ * bsx.h -- C-ABI of the MI355X (gfx950) Boolean-network state-update engine.
+ *
+ * This is the drop-in boundary for BoolSi's simulate / attract / target hot path.  The reference
+ * (pure Python, /root/reference) has no FFI; the seam it offers is the per-batch function
+ *     execute_task(task, solve, store, empty_results, n_to_find)        boolsi/mpi.py:498-544
+ * with task = (batch seed, batch index, predecessor_node_lists, truth_tables)
+ *                                                                       boolsi/batching.py:313-316
+ * and the solver bound by configure_solve_simulation_problem            boolsi/mpi.py:351-376.
+ * One bsx_run_* call does the work of execute_task over a contiguous range of the problem
+ * index: enumerate -> adjust rules for fixed nodes -> solve -> store/aggregate.
+ *
+ * Conventions
+ *   - plain C, caller-allocated host buffers, no callbacks, no torch / numpy types;
+ *   - every function returns BSX_OK (0) or a negative bsx_status; bsx_last_error() gives text;
+ *   - one handle per device; a handle is not thread-safe, distinct handles are independent;
+ *   - there is NO CPU implementation behind this API: bsx_create fails without a gfx950 device.
+ *
+ * State layout: a state is W = ceil(n/64) uint64 words, node i = bit (i % 64) of
+ * word i / 64, so that the reference's state code (model.py:131-149) is the little-endian
+ * big integer formed by the words.
+ */
+#ifndef BSX_H
+#define BSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSX_MAX_NODES        256
+#define BSX_MAX_WORDS        4      /* uint64 words per state / key */
+#define BSX_MAX_PREDECESSORS 24
+#define BSX_MAX_PERT_VARIATIONS 32
+#define BSX_T_INF            UINT64_MAX   /* "no cap" for max_t / max_len (the CLI's inf) */
+
+typedef enum {
+    BSX_OK = 0,
+    BSX_ERR_INVALID = -1,        /* bad argument / inconsistent tables */
+    BSX_ERR_NO_DEVICE = -2,      /* no gfx950 GPU, or HIP runtime failure at create */
+    BSX_ERR_HIP = -3,            /* HIP call failed (text in bsx_last_error) */
+    BSX_ERR_UNSUPPORTED = -4,    /* network exceeds an engine limit (BSX_MAX_*) */
+    BSX_ERR_TABLE_FULL = -5,     /* more distinct attractors / hits than the caller's capacity */
+    BSX_ERR_STEP_LIMIT = -6,     /* a trajectory ran into the engine's internal step limit
+                                    (only possible when max_t is BSX_T_INF or above that limit) */
+    BSX_ERR_STATE = -7           /* call order: network / problem space not set */
+} bsx_status;
+
+/* Variation ranges = boolsi.constants.NodeStateRange (constants.py:23-30), digit -> state as in
+ * batching.py:171-175. */
+enum {
+    BSX_RANGE_MAYBE_FALSE = 0,          /* '0?'   digit 0: absent, 1: 0           radix 2 */
+    BSX_RANGE_MAYBE_TRUE = 1,           /* '1?'   digit 0: absent, 1: 1           radix 2 */
+    BSX_RANGE_TRUE_OR_FALSE = 2,        /* 'any'  digit 0: 0,      1: 1           radix 2 */
+    BSX_RANGE_MAYBE_TRUE_OR_FALSE = 3   /* 'any?' digit 0: absent, 1: 0, 2: 1     radix 3 */
+};
+
+typedef struct bsx_engine* bsx_handle;
+
+/* Problem index I of the reference's mixed-radix enumeration (batching.py:10-46, 212-229), split
+ * at the initial-state digits:  I = init_digits + variant * 2^n_any.
+ *   init_digits: n_any binary digits, digit j = state of the j-th 'any' initial node (node order),
+ *                packed little-endian into uint64 words (so I mod 2^n_any);
+ *   variant:     the remaining digits (fixed-node variations, then perturbation variations) as one
+ *                number, I >> n_any.  Must fit 64 bits. */
+typedef struct {
+    uint64_t init_digits[BSX_MAX_WORDS];
+    uint64_t variant;
+} bsx_index;
+
+typedef struct { uint32_t node; uint32_t value; } bsx_fixed;              /* origin fixed node (model.py:31-49) */
+typedef struct { uint32_t node; uint32_t range; } bsx_fixed_var;          /* fixed-node variation */
+typedef struct { uint32_t t; uint32_t node; uint32_t value; } bsx_pert;   /* origin perturbation at time t >= 1 */
+typedef struct { uint32_t t; uint32_t node; uint32_t range; } bsx_pert_var;
+
+/* One aggregated attractor = reference AggregatedAttractor (attract.py:18-45) with the float
+ * mean / M2 replaced by exact integer sums: mean = sum_l / count, M2 = sum_l2 - sum_l^2 / count. */
+typedef struct {
+    uint64_t key[BSX_MAX_WORDS];   /* min state code over the cycle (attract.py:296) */
+    uint64_t length;               /* attractor length */
+    uint64_t count;                /* frequency */
+    uint64_t sum_l;                /* sum of trajectory_l = T_p + mu (attract.py:291-298) */
+    uint64_t sum_l2_lo, sum_l2_hi; /* 128-bit sum of trajectory_l^2 */
+} bsx_attr_rec;
+
+/* Optional per-problem result of attract (what store_attractor receives, attract.py:374-402). */
+typedef struct {
+    uint64_t key[BSX_MAX_WORDS];
+    uint64_t length;
+    uint64_t trajectory_l;
+    uint32_t found;                /* 0: no attractor within max_t / max_len */
+    uint32_t pad;
+} bsx_problem_rec;
+
+/* target: one simulation that reached the target substate (target.py:109-133). */
+typedef struct {
+    uint64_t offset;               /* problem = first + offset */
+    uint64_t t;                    /* first t >= T_p with state & mask == code */
+} bsx_hit;
+
+typedef struct {
+    uint64_t problems;             /* problems processed */
+    uint64_t state_steps;          /* steps the reference algorithm performs for them (S5-S7):
+                                      t_stop per problem; simulate: max_t per problem */
+    uint64_t executed_steps;       /* network updates the kernels actually executed */
+    double   kernel_ms;            /* device time of the hot kernels (HIP events on the engine's stream) */
+    double   total_ms;             /* wall time of the call incl. uploads, merge, downloads */
+    uint32_t kernel_launches;
+    uint32_t pad;
+} bsx_stats;
+
+int  bsx_create(bsx_handle* out, int device);
+int  bsx_destroy(bsx_handle h);
+const char* bsx_last_error(bsx_handle h);       /* h may be NULL: error of the last failed bsx_create */
+const char* bsx_status_string(int status);
+int  bsx_device_info(bsx_handle h, char* name, uint32_t name_cap, uint32_t* compute_units,
+                     uint64_t* global_mem_bytes);
+
+/* Network = (predecessor_node_lists, truth_tables) of the task tuple (batching.py:313-316).
+ * pred_idx: predecessors of node i are pred_idx[pred_offsets[i] .. pred_offsets[i+1]) ascending
+ * (input.py:796).  tt_words: table of node i starts at word tt_word_offsets[i] and has 2^k bits;
+ * bit idx = output when predecessor j has state (idx >> j) & 1  (SURVEY.md S2). */
+int  bsx_set_network(bsx_handle h, uint32_t n_nodes,
+                     const uint32_t* pred_offsets, const uint32_t* pred_idx,
+                     const uint32_t* tt_word_offsets, const uint64_t* tt_words);
+
+/* Problem space = (origin_simulation_problem, simulation_problem_variations) of the batch seed
+ * (batching.py:258-282, input.py:148-157); variation arrays in the reference's list order. */
+int  bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_words,
+                           const uint32_t* any_nodes, uint32_t n_any,
+                           const bsx_fixed* fixed, uint32_t n_fixed,
+                           const bsx_fixed_var* fixed_var, uint32_t n_fixed_var,
+                           const bsx_pert* sched, uint32_t n_sched,
+                           const bsx_pert_var* pert_var, uint32_t n_pert_var);
+
+/* attract (attract.py:262-302 semantics for every problem of [first, first + count)):
+ * aggregated table (unordered) into table[0..*n_out), problems without attractor counted in
+ * *n_no_attractor.  per_problem (count entries) may be NULL. */
+int  bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count,
+                     uint64_t max_t, uint64_t max_len,
+                     bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
+                     uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats);
+
+/* target (target.py:109-133): hits (unordered) into hits[0..*n_hits); mask/code are W words
+ * (target node set / target substate code, input.py:580-661). */
+int  bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                    const uint64_t* mask_words, const uint64_t* code_words,
+                    bsx_hit* hits, uint64_t cap, uint64_t* n_hits, bsx_stats* stats);
+
+/* simulate (simulate.py:97-131 == s(0..max_t) by plain stepping): any of the three sinks may
+ * be NULL.  trajectories[(p * (max_t + 1) + t) * W + w], final_states[p * W + w], digests[p]
+ * (FNV-1a over the words of s(0..max_t)). */
+int  bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                      uint64_t* trajectories, uint64_t* final_states, uint64_t* digests,
+                      bsx_stats* stats);
+
+/* trajectories s(0..t_len[q]) of listed problems (first + offsets[q]); used to materialise the
+ * simulations of target hits.  out[q] starts at out_offsets[q] words. */
+int  bsx_run_trajectories(bsx_handle h, const bsx_index* first, const uint64_t* offsets,
+                          const uint64_t* t_len, uint64_t n, uint64_t* out,
+                          const uint64_t* out_offsets, bsx_stats* stats);
+
+/* Blocks until all work of the handle's stream is done (bench.py's timing fence). */
+int  bsx_synchronize(bsx_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSX_H */
