@@ -1,0 +1,158 @@
+"""
+Attract mode: finds and aggregates attractors over a range of simulation problems.
+
+Mirrors the reference's `boolsi/attract.py`:
+  AggregatedAttractor (18-45) ........ same fields; mean / M2 derived once from exact integer sums
+  attract_master (67-230) ............ `attract_master` below: engine runs over index tiles, merge,
+                                       final order = ascending (-frequency, key) (170-173)
+  store_attractor / write_aggregated_attractors_to_db (374-455) ... merge_tables
+The per-problem solvers (262-371) run on the GPU (bsx_run_attract).  The reduce-memory flag (-r)
+is accepted and ignored: the device detector is already O(1) memory and yields the default
+detector's result (S7); see DESIGN.md for the reference's -r/-t defect that is not reproduced.
+"""
+import logging
+from math import inf
+
+import numpy as np
+
+from .compile import compile_network, compile_space, code_to_words, words_to_code
+from .dist import Comm, partition
+from .engine import key_to_int
+from .model import decode_state
+
+MAX_TILE = 1 << 32      # problems per engine call
+
+
+class AggregatedAttractor:
+    """Attractor with its basin statistics (reference attract.py:18-45)."""
+
+    def __init__(self, key, length, frequency, sum_l, sum_l2, states=None):
+        self.key = key
+        self.length = length
+        self.frequency = frequency
+        self.sum_l = sum_l
+        self.sum_l2 = sum_l2
+        self.states = states        # list of lists of bool, first state = key state
+
+    @property
+    def trajectory_l_mean(self):
+        return self.sum_l / self.frequency
+
+    @property
+    def trajectory_l_variation_sum(self):
+        # M2 = sum (l - mean)^2, from integers: (c*S2 - S1^2) / c
+        return (self.frequency * self.sum_l2 - self.sum_l * self.sum_l) / self.frequency
+
+
+def merge_tables(tables):
+    """List of bsx_attr_rec arrays -> dict key(int) -> [length, count, sum_l, sum_l2] (exact ints)."""
+    merged = {}
+    for table in tables:
+        for a in table:
+            key = key_to_int(a['key'])
+            e = merged.get(key)
+            if e is None:
+                merged[key] = [int(a['length']), int(a['count']), int(a['sum_l']),
+                               int(a['sum_l2_lo']) + (int(a['sum_l2_hi']) << 64)]
+            else:
+                if e[0] != int(a['length']):
+                    raise RuntimeError('attractor {} reported with two lengths'.format(key))
+                e[1] += int(a['count'])
+                e[2] += int(a['sum_l'])
+                e[3] += int(a['sum_l2_lo']) + (int(a['sum_l2_hi']) << 64)
+    return merged
+
+
+def table_from_merged(merged, dtype):
+    out = np.zeros(len(merged), dtype)
+    for i, (key, (length, count, s1, s2)) in enumerate(sorted(merged.items())):
+        for w in range(4):
+            out[i]['key'][w] = (key >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+        out[i]['length'], out[i]['count'], out[i]['sum_l'] = length, count, s1
+        out[i]['sum_l2_lo'], out[i]['sum_l2_hi'] = s2 & 0xFFFFFFFFFFFFFFFF, s2 >> 64
+    return out
+
+
+def run_attract_range(engine, first, count, max_t=inf, max_attractor_l=inf, cap=1 << 20):
+    """Engine over [first, first+count) in tiles -> (merged dict, n_no_attractor, stats dict)."""
+    merged_tables, none = [], 0
+    stats = {'problems': 0, 'state_steps': 0, 'executed_steps': 0, 'kernel_ms': 0.0, 'total_ms': 0.0,
+             'kernel_launches': 0}
+    done = 0
+    while done < count:
+        tile = min(MAX_TILE, count - done)
+        r = engine.attract(first + done, tile, max_t, max_attractor_l, cap=cap)
+        merged_tables.append(r.table)
+        none += r.n_no_attractor
+        for k in stats:
+            stats[k] += r.stats[k]
+        done += tile
+    return merge_tables(merged_tables), none, stats
+
+
+def attract_master(engine, origin_simulation_problem, simulation_problem_variations,
+                   predecessor_node_lists, truth_tables, max_t, max_attractor_l,
+                   n_simulation_problems, comm=None, with_states=True):
+    """
+    Attract over the whole problem space, range-partitioned over `comm` (one rank per GPU).
+    Returns (list of AggregatedAttractor in final order, n_no_attractor, total_frequency, stats);
+    identical on every rank.  Log lines follow attract.py:95-138.
+    """
+    comm = comm or Comm()
+    log = logging.getLogger()
+    n_processes_text = '{} GPU processes'.format(comm.world) if comm.world > 1 else 'Single process'
+    if comm.rank == 0:
+        log.info('{} will be used to find attractors from {} initial conditions...'.format(
+            n_processes_text, n_simulation_problems))
+
+    net = compile_network(predecessor_node_lists, truth_tables)
+    space = compile_space(origin_simulation_problem, simulation_problem_variations)
+    engine.set_problem(net, space)
+    first, count = partition(n_simulation_problems, comm.world, comm.rank)
+    merged, none, stats = run_attract_range(engine, first, count, max_t, max_attractor_l)
+
+    if comm.world > 1:
+        from . import _lib
+        tables = comm.allgather_records(table_from_merged(merged, _lib.ATTR_REC))
+        merged = merge_tables(tables)
+        none, steps, execd = comm.allreduce_sum_int([none, stats['state_steps'], stats['executed_steps']])
+        stats['state_steps'], stats['executed_steps'] = steps, execd
+        stats['problems'] = n_simulation_problems
+
+    total_frequency = sum(e[1] for e in merged.values())
+    assert total_frequency + none == n_simulation_problems
+
+    if comm.rank == 0:
+        parts = ['Found {} attractors.'.format(len(merged))]
+        if total_frequency < n_simulation_problems:
+            p = ['No attractor']
+            if max_attractor_l < inf:
+                p.append('of length {} or less'.format(max_attractor_l))
+            p.append('can be')
+            if max_t < inf:
+                p.append('detected in')
+                p.append('1 time step' if max_t == 1 else '{} or less time steps'.format(max_t))
+            else:
+                p.append('reached')
+            p.append('from {:.2%} initial conditions.'.format(1 - total_frequency / n_simulation_problems))
+            parts.append(' '.join(p))
+        log.info(' '.join(parts))
+
+    order = sorted(merged.items(), key=lambda kv: (-kv[1][1], kv[0]))     # attract.py:170-173
+    attractors = []
+    for key, (length, freq, s1, s2) in order:
+        states = None
+        if with_states:
+            states = cycle_states(engine, key, length)
+        attractors.append(AggregatedAttractor(key, length, freq, s1, s2, states))
+    return attractors, none, total_frequency, stats
+
+
+def cycle_states(engine, key, length):
+    """
+    States of the attractor, starting at its key state (attract.py:22-25 rotation).  Regenerated on
+    the device by stepping from the key under the origin problem's fixed nodes (attract mode allows
+    no fixed-node variations, input.py:392-397, so every problem shares them).
+    """
+    states = engine.states_from(key, length - 1)
+    return [decode_state(words_to_code(s), engine.net.n_nodes) for s in states]

@@ -1,0 +1,112 @@
+"""
+Multi-GPU layer: one process per GPU, problems range-partitioned, one all-gather at the end.
+
+Replaces the reference's mpi4py master/worker task farm (boolsi/mpi.py:193-340, 379-495): the
+simulation problems are independent, so rank r simply takes the contiguous index range
+[r*N/G, (r+1)*N/G) and the only communication is the merge of the per-rank attractor tables --
+`torch.distributed.all_gather` of fixed-size integer records (backend "nccl" = RCCL over xGMI on
+GPUs, "gloo" on CPU for the tests).  torch is used for this control/collective plumbing only and is
+imported lazily, so single-GPU runs never load it.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+class Comm:
+    """World of size 1 unless initialised from the torchrun environment."""
+
+    def __init__(self):
+        self.rank = 0
+        self.world = 1
+        self.local_rank = 0
+        self.backend = None
+        self._dist = None
+        self._torch = None
+
+    @classmethod
+    def from_env(cls, backend=None):
+        c = cls()
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if world <= 1 and not os.environ.get('BSX_FORCE_DIST'):
+            return c
+        import torch
+        import torch.distributed as dist
+        c.rank = int(os.environ.get('RANK', '0'))
+        c.world = world
+        c.local_rank = int(os.environ.get('LOCAL_RANK', c.rank))
+        c.backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if c.backend == 'nccl':
+            torch.cuda.set_device(c.local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=c.backend, rank=c.rank, world_size=world)
+        c._dist, c._torch = dist, torch
+        return c
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _device(self):
+        return self._torch.device('cuda', self.local_rank) if self.backend == 'nccl' else self._torch.device('cpu')
+
+    def barrier(self):
+        if self.world > 1:
+            self._dist.barrier()
+            if self.backend == 'nccl':
+                self._torch.cuda.synchronize()
+
+    def allreduce_max(self, value):
+        if self.world == 1:
+            return float(value)
+        t = self._torch.tensor([float(value)], dtype=self._torch.float64, device=self._device())
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allreduce_sum_int(self, values):
+        """Element-wise sum of a list of non-negative python ints (< 2^62 each) over ranks."""
+        if self.world == 1:
+            return [int(v) for v in values]
+        t = self._torch.tensor([int(v) for v in values], dtype=self._torch.int64, device=self._device())
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return [int(v) for v in t.tolist()]
+
+    def allgather_records(self, records):
+        """
+        All-gather a 1-D numpy structured array (e.g. _lib.ATTR_REC) -> list of per-rank arrays.
+        One collective for the counts, one for the records padded to the common maximum.
+        """
+        if self.world == 1:
+            return [records]
+        torch, dist = self._torch, self._dist
+        dev = self._device()
+        n = torch.tensor([len(records)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(counts, n)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        item = records.dtype.itemsize
+        buf = np.zeros(cap * item, np.uint8)
+        buf[:len(records) * item] = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+        mine = torch.from_numpy(buf).to(dev)
+        gathered = torch.empty(self.world * cap * item, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, mine)
+        host = gathered.cpu().numpy()
+        out = []
+        for r, c in enumerate(counts):
+            chunk = host[r * cap * item:(r * cap + c) * item]
+            out.append(np.frombuffer(chunk.tobytes(), dtype=records.dtype))
+        return out
+
+    def shutdown(self):
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
+
+def partition(n_problems, world, rank):
+    """Contiguous index range of `rank`: [r*N/G, (r+1)*N/G)."""
+    lo = (n_problems * rank) // world
+    hi = (n_problems * (rank + 1)) // world
+    return lo, hi - lo
+
+
+ATTR_REC = _lib.ATTR_REC

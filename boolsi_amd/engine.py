@@ -91,6 +91,11 @@ class Engine:
         a = [np.ascontiguousarray(x) for x in (net.pred_offsets, net.pred_idx, net.tt_word_offsets,
                                                net.tt_words)]
         self._check(self._lib.bsx_set_network(self._h, net.n_nodes, ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3])))
+        self.net = net
+        self._keep_net = a
+        self.set_space(space)
+
+    def set_space(self, space):
         b = [np.ascontiguousarray(space.origin_state, np.uint64),
              np.ascontiguousarray(space.any_nodes, np.uint32),
              np.ascontiguousarray(space.fixed, np.uint32), np.ascontiguousarray(space.fixed_var, np.uint32),
@@ -98,8 +103,29 @@ class Engine:
         self._check(self._lib.bsx_set_problem_space(
             self._h, ptr(b[0]), ptr(b[1]), len(b[1]), ptr(b[2]), len(b[2]), ptr(b[3]), len(b[3]),
             ptr(b[4]), len(b[4]), ptr(b[5]), len(b[5])))
-        self.net, self.space = net, space
-        self._keep = a + b
+        self.space = space
+        self._keep = b
+
+    def states_from(self, state_code, n_steps):
+        """
+        s, f(s), ..., f^n_steps(s) for the state with code `state_code`, under the origin problem's
+        constant fixed nodes and without perturbations -> (n_steps + 1, W) uint64 array.
+        Used to list the states of an attractor from its key (reference attract.py:22-25 keeps
+        them in memory instead).
+        """
+        from .compile import CompiledSpace, code_to_words
+        saved = self.space
+        empty2 = np.zeros((0, 2), np.uint32)
+        empty3 = np.zeros((0, 3), np.uint32)
+        tmp = CompiledSpace(n_nodes=self.net.n_nodes, origin_state=code_to_words(state_code, self.net.n_words),
+                            any_nodes=np.zeros(0, np.uint32), fixed=saved.fixed, fixed_var=empty2, sched=empty3,
+                            pert_var=empty3, n_problems=1, radices=[])
+        self.set_space(tmp)
+        try:
+            trajs, _ = self.trajectories(0, [0], [n_steps])
+        finally:
+            self.set_space(saved)
+        return trajs[0]
 
     def index(self, i):
         """python int problem index -> bsx_index (split at the initial-state digits)."""
