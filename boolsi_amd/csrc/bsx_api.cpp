@@ -200,7 +200,7 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
         else k_mux = std::max(k_mux, k);
     }
 
-    const uint32_t n_chunks = (n_nodes + 7) / 8;
+    const uint32_t n_chunks = nw * 4;       // zero entries for the bytes beyond n keep the gather branch-free
     std::vector<uint32_t> masks((size_t)(1u << k_mux) * nw, 0);
     std::vector<uint32_t> lut((size_t)n_chunks * 256 * k_mux * nw, 0);
     for (uint32_t i = 0; i < n_nodes; ++i) {

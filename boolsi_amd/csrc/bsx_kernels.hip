@@ -20,8 +20,12 @@
 
 namespace bsx {
 
+// (a & sel) | (b & ~sel) in one VALU op.  Written as asm because with loop-invariant a/b the compiler
+// prefers two ops (and + xor with a precomputed a^b), which doubles the cost of the mux tree.
 __device__ __forceinline__ uint32_t bfi(uint32_t sel, uint32_t a, uint32_t b) {
-    return (a & sel) | (b & ~sel);      // v_bfi_b32
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(sel), "v"(a), "v"(b));
+    return r;
 }
 
 template <int NW>
@@ -35,6 +39,9 @@ __device__ __forceinline__ bool eq_words(const uint32_t (&a)[NW], const uint32_t
 // a < b as big integers, word NW-1 most significant (state code order, model.py:131-149)
 template <int NW>
 __device__ __forceinline__ bool lt_words(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
+    if constexpr (NW == 1) return a[0] < b[0];
+    if constexpr (NW == 2)
+        return (((uint64_t)a[1] << 32) | a[0]) < (((uint64_t)b[1] << 32) | b[0]);     // v_cmp_lt_u64
     bool lt = false, eq = true;
 #pragma unroll
     for (int w = NW - 1; w >= 0; --w) {
@@ -76,9 +83,10 @@ __device__ __forceinline__ void put_bit(uint32_t (&s)[NW], uint32_t node, uint32
 // Network tables as seen by a workgroup: LUT and masks either in LDS or (large networks) in HBM/L2.
 template <int NW, int K>
 struct NetView {
+    static constexpr bool kMasksInRegs = (K <= 3);
     const uint32_t* lut;     // LDS or global
-    const uint32_t* masks;   // LDS
-    uint32_t n_chunks;
+    const uint32_t* masks;   // LDS (used when the 2^K * NW mask words do not fit the register budget)
+    uint32_t mreg[kMasksInRegs ? (1 << K) * NW : 1];
     uint32_t n_wide;
     const uint32_t* wide_desc;
     const uint32_t* wide_preds;
@@ -119,18 +127,31 @@ __device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_
 #pragma unroll
         for (int w = 0; w < NW; ++w) g[j][w] = 0;
 
-    // gather: one LUT entry per 8 state bits
+    // gather: one LUT entry per 8 state bits.  All NW*4 lookups are issued unconditionally (the LUT
+    // is zero-padded to whole 32-bit words of state) so the LDS reads overlap instead of each
+    // waiting behind a branch.
+    // Lookups are issued in batches sized to keep the in-flight entries within ~64 registers.
+    constexpr int kEntry = K * NW;
+    constexpr int kBatch = (64 / kEntry) < 1 ? 1 : ((64 / kEntry) > NW * 4 ? NW * 4 : (64 / kEntry));
 #pragma unroll
-    for (int ch = 0; ch < NW * 4; ++ch) {
-        if ((uint32_t)ch < nv.n_chunks) {
-            const uint32_t v = (s[ch >> 2] >> ((ch & 3) * 8)) & 0xFFu;
-            uint32_t e[K * NW];
-            load_entry<K * NW>(nv.lut + ((uint32_t)(ch << 8) + v) * (K * NW), e);
+    for (int c0 = 0; c0 < NW * 4; c0 += kBatch) {
+        uint32_t e[kBatch][kEntry];
 #pragma unroll
-            for (int j = 0; j < K; ++j)
-#pragma unroll
-                for (int w = 0; w < NW; ++w) g[j][w] |= e[j * NW + w];
+        for (int b = 0; b < kBatch; ++b) {
+            const int ch = c0 + b;
+            if (ch < NW * 4) {
+                const uint32_t v = (s[ch >> 2] >> ((ch & 3) * 8)) & 0xFFu;
+                load_entry<kEntry>(nv.lut + ((uint32_t)(ch << 8) + v) * kEntry, e[b]);
+            }
         }
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b)
+            if (c0 + b < NW * 4) {
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) g[j][w] |= e[b][j * NW + w];
+            }
     }
 
     // mux tree over the bit-packed truth-table masks: level j selects on predecessor slot j
@@ -139,7 +160,9 @@ __device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_
     for (int i = 0; i < (1 << (K - 1)); ++i)
 #pragma unroll
         for (int w = 0; w < NW; ++w)
-            r[i][w] = bfi(g[0][w], nv.masks[(2 * i + 1) * NW + w], nv.masks[(2 * i) * NW + w]);
+            r[i][w] = NetView<NW, K>::kMasksInRegs
+                          ? bfi(g[0][w], nv.mreg[(2 * i + 1) * NW + w], nv.mreg[(2 * i) * NW + w])
+                          : bfi(g[0][w], nv.masks[(2 * i + 1) * NW + w], nv.masks[(2 * i) * NW + w]);
 #pragma unroll
     for (int j = 1; j < K; ++j)
 #pragma unroll
@@ -297,7 +320,12 @@ __device__ __forceinline__ NetView<NW, K> stage_network(const DevNet& net, uint3
     }
     __syncthreads();
     nv.masks = smasks;
-    nv.n_chunks = net.n_chunks;
+    if constexpr (NetView<NW, K>::kMasksInRegs) {
+#pragma unroll
+        for (int i = 0; i < (1 << K) * NW; ++i) nv.mreg[i] = smasks[i];
+    } else {
+        nv.mreg[0] = 0;
+    }
     nv.n_wide = net.n_wide;
     nv.wide_desc = net.wide_desc;
     nv.wide_preds = net.wide_preds;
@@ -374,9 +402,15 @@ __device__ __forceinline__ void table_merge(const AttractParams& P, TableSlot<NW
     }
 }
 
-enum Phase : uint32_t { PH_IDLE = 0, PH_WARM = 1, PH_BRENT = 2, PH_ADVANCE = 3, PH_MU = 4 };
+// Lane phases.  PH_DONE = result computed, waiting for the wave's next service round.
+enum Phase : uint32_t { PH_IDLE = 0, PH_DONE = 1, PH_WARM = 2, PH_BRENT = 3, PH_ADVANCE = 4, PH_MU = 5 };
 
-// Wave-level dequeue of problem offsets.  Returns false when the wave is done.
+// Results are recorded and free lanes refilled in "service rounds", entered when at least this many
+// lanes of the wave are waiting.  Enumeration (index -> problem) and aggregation are ~5x the cost of
+// a network update, so they are run for several lanes at once instead of whenever one lane finishes.
+constexpr uint32_t kServiceLanes = 8;
+
+// Wave-level dequeue of problem offsets.
 struct WaveQueue {
     uint64_t next, end;
     bool more;
@@ -396,6 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
     uint32_t* smem_free;
     const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
+    const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;      // wave-uniform
     TableSlot<NW> slot;
 #pragma unroll
     for (int w = 0; w < NW; ++w) slot.key[w] = 0;
@@ -404,8 +439,10 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
     uint32_t A[NW], B[NW], C[NW], D[NW], fm[NW], fv[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) { A[w] = B[w] = C[w] = D[w] = 0; fm[w] = fv[w] = 0; }
+    // t: steps since T_p (Brent) / absolute time (warm-up); cnt: pointer advance / mu; sub: which
+    // pointer moves next in PH_MU, and the found flag while in PH_DONE
     uint32_t phase = PH_IDLE, t = 0, tp = 0, lam = 0, power = 1, cnt = 0, sub = 0;
-    uint32_t brent_limit = 0, cap_rel = 0;
+    uint32_t brent_limit = 0, cap_rel = 0, exec32 = 0;
     uint64_t pv_digits = 0, my_p = 0;
 
     uint32_t ck[NW];
@@ -420,37 +457,79 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
     WaveQueue q{0, 0, true};
 
     for (;;) {
-        // ---- refill idle lanes with the next problems of the wave's chunk
-        const uint64_t idle = __ballot(phase == PH_IDLE);
-        if (idle) {
-            if (q.next == q.end && q.more) {
-                const uint64_t base = grab_chunk(&P.ctr->cursor, P.chunk, lane);
-                if (base >= P.count) q.more = false;
-                else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
-            }
-            const uint64_t avail = q.end - q.next;
-            if (avail) {
-                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
-                if (phase == PH_IDLE && rank < avail) {
-                    Problem<NW> pr;
-                    my_p = q.next + rank;
-                    init_problem<NW>(P.sp, my_p, pr);
-                    copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
-                    pv_digits = pr.pv_digits; tp = pr.tp; t = 0;
-                    // found iff mu + lambda <= max_t - T_p (S7); Brent needs at most 3x that many steps
-                    if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
-                    else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
-                    if (tp > 0) phase = PH_WARM;
-                    else {
-                        phase = PH_BRENT; lam = 0; power = 1;
-                        copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+        const uint32_t n_run = __popcll(__ballot(phase >= PH_WARM));
+        const uint32_t n_pend = __popcll(__ballot(phase == PH_DONE));
+        const uint32_t n_wait = 64u - n_run;                       // pending + idle
+        const bool work_left = q.more || q.next < q.end;
+        if (n_run == 0 && n_pend == 0 && !work_left) break;
+        const bool service = (n_pend && (n_pend >= kServiceLanes || n_run == 0 || !work_left)) ||
+                             (work_left && (n_wait >= kServiceLanes || n_run == 0));
+        if (service) {
+            // ---- resolved problems: statistics, per-problem record, aggregation
+            bool flush = false;
+            uint32_t fk[NW], flen = 0, fcnt = 0;
+            uint64_t fsl = 0, fsl2 = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) fk[w] = 0;
+            if (phase == PH_DONE) {
+                phase = PH_IDLE;
+                const bool found = sub != 0;
+                const uint64_t traj_l = (uint64_t)tp + cnt;
+                steps_exec += exec32;
+                // reference loop stops at T_p + mu + lambda when found, at max_t otherwise (model.py:201)
+                steps_ref += found ? traj_l + lam : (P.cap_rel_inf ? 0ull : P.max_t);
+                const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
+                if (P.per_problem) {
+                    ProblemRec32 r;
+#pragma unroll
+                    for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
+                    if (keep) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) r.key[w] = C[w];
                     }
+                    r.length = keep ? lam : 0; r.trajectory_l = keep ? (uint32_t)traj_l : 0; r.found = keep; r.pad = 0;
+                    P.per_problem[my_p] = r;
                 }
-                const uint64_t taken = (uint64_t)__popcll(idle) < avail ? (uint64_t)__popcll(idle) : avail;
-                q.next += taken;
-            } else if (!q.more && idle == ~0ull) {
-                break;
+                if (!keep) ++n_none;
+                else if (ccnt && eq_words<NW>(ck, C) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += traj_l * traj_l; }
+                else {
+                    if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
+                    copy_words<NW>(ck, C); clen = lam; ccnt = 1; csl = traj_l; csl2 = traj_l * traj_l;
+                }
             }
+            if (__ballot(flush)) table_merge<NW>(P, slot, lane, flush, fk, flen, fcnt, fsl, fsl2);
+
+            // ---- refill idle lanes with the next problems of the wave's chunk
+            if (work_left) {
+                if (q.next == q.end) {
+                    const uint64_t base = grab_chunk(&P.ctr->cursor, P.chunk, lane);
+                    if (base >= P.count) q.more = false;
+                    else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
+                }
+                const uint64_t avail = q.end - q.next;
+                const uint64_t idle = __ballot(phase == PH_IDLE);
+                if (avail && idle) {
+                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    if (phase == PH_IDLE && rank < avail) {
+                        Problem<NW> pr;
+                        my_p = q.next + rank;
+                        init_problem<NW>(P.sp, my_p, pr);
+                        copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
+                        pv_digits = pr.pv_digits; tp = pr.tp; t = 0; exec32 = 0;
+                        // found iff mu + lambda <= max_t - T_p (S7); Brent needs at most 3x that many steps
+                        if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
+                        else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
+                        if (tp > 0) phase = PH_WARM;
+                        else {
+                            phase = PH_BRENT; lam = 0; power = 1;
+                            copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+                        }
+                    }
+                    const uint64_t n_idle = (uint64_t)__popcll(idle);
+                    q.next += n_idle < avail ? n_idle : avail;
+                }
+            }
+            continue;       // re-evaluate the wave state (nothing to step if every lane is idle)
         }
 
         // ---- one network update per lane per iteration
@@ -459,12 +538,10 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) cur[w] = step_b ? B[w] : A[w];
         net_step<NW, K>(nv, cur, fm, fv, nxt);
+        exec32 += (phase >= PH_WARM) ? 1u : 0u;
 
-        bool finished = false, found = false;
-        uint32_t mu = 0;
-
-        if (phase == PH_WARM) {
-            ++t; ++steps_exec;
+        if (has_warmup && phase == PH_WARM) {
+            ++t;
             apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
             copy_words<NW>(A, nxt);
             if (t == tp) {
@@ -472,65 +549,40 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                 copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
             }
         } else if (phase == PH_BRENT) {
-            ++t; ++lam; ++steps_exec;
+            ++t; ++lam;
             copy_words<NW>(A, nxt);
             if (eq_words<NW>(A, B)) {
                 // cycle closed: lam = attractor length, C = min code seen since the tortoise moved = key
-                if (lam > cap_rel) finished = true;          // lambda alone exceeds max_t - T_p: not found
+                if (lam > cap_rel) { phase = PH_DONE; sub = 0; cnt = 0; }   // lambda alone exceeds max_t - T_p
                 else { phase = PH_ADVANCE; cnt = 0; copy_words<NW>(A, D); copy_words<NW>(B, D); }
             } else {
                 if (lt_words<NW>(A, C)) copy_words<NW>(C, A);
                 if (lam == power) { copy_words<NW>(B, A); copy_words<NW>(C, A); power <<= 1; lam = 0; }
                 if (t >= brent_limit) {
-                    finished = true;
+                    phase = PH_DONE; sub = 0; cnt = 0;
                     if (cap_rel == 0xFFFFFFFFu) ++limit_hits;
                 }
             }
         } else if (phase == PH_ADVANCE) {
-            ++steps_exec; ++cnt;
+            // second pointer y = A moves lambda steps ahead of x = B = s(T_p)
+            ++cnt;
             copy_words<NW>(A, nxt);
-            if (cnt == lam) { phase = PH_MU; cnt = 0; sub = 0; }
+            if (cnt == lam) {
+                cnt = 0; sub = 0;
+                if (eq_words<NW>(A, B)) { phase = PH_DONE; sub = 1; }                       // mu = 0
+                else if (lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { phase = PH_DONE; }     // mu >= 1: mu + lam > cap
+                else phase = PH_MU;
+            }
         } else if (phase == PH_MU) {
-            if (!sub) {
-                if (eq_words<NW>(A, B)) { finished = true; found = true; mu = cnt; }
-                else if (cnt + lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { finished = true; }   // mu + lam > cap
-                else { copy_words<NW>(A, nxt); sub = 1; ++steps_exec; }
-            } else {
-                copy_words<NW>(B, nxt); sub = 0; ++cnt; ++steps_exec;
-            }
-        }
-
-        // ---- resolved problems: statistics, per-problem record, aggregation
-        bool flush = false;
-        uint32_t fk[NW], flen = 0, fcnt = 0;
-        uint64_t fsl = 0, fsl2 = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) fk[w] = 0;
-        if (finished) {
-            phase = PH_IDLE;
-            const uint64_t traj_l = (uint64_t)tp + mu;
-            // reference loop stops at T_p + mu + lambda when found, at max_t otherwise (model.py:201)
-            steps_ref += found ? traj_l + lam : (P.cap_rel_inf ? 0ull : P.max_t);
-            const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
-            if (P.per_problem) {
-                ProblemRec32 r;
-#pragma unroll
-                for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
-                if (keep) {
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) r.key[w] = C[w];
-                }
-                r.length = keep ? lam : 0; r.trajectory_l = keep ? (uint32_t)traj_l : 0; r.found = keep; r.pad = 0;
-                P.per_problem[my_p] = r;
-            }
-            if (!keep) ++n_none;
-            else if (ccnt && eq_words<NW>(ck, C) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += traj_l * traj_l; }
+            // lagged two-pointer pass, one network update per iteration: y, then x, then compare
+            if (!sub) { copy_words<NW>(A, nxt); sub = 1; }
             else {
-                if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
-                copy_words<NW>(ck, C); clen = lam; ccnt = 1; csl = traj_l; csl2 = traj_l * traj_l;
+                copy_words<NW>(B, nxt); ++cnt;
+                if (eq_words<NW>(A, B)) { phase = PH_DONE; sub = 1; }                       // mu = cnt
+                else if (cnt + lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { phase = PH_DONE; sub = 0; cnt = 0; }
+                else sub = 0;
             }
         }
-        if (__ballot(flush)) table_merge<NW>(P, slot, lane, flush, fk, flen, fcnt, fsl, fsl2);
     }
 
     // ---- epilogue: lane caches -> wave table -> HBM log; counters

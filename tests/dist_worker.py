@@ -1,0 +1,45 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-N gloo job (CPU)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+
+from boolsi_amd import synth, _lib  # noqa: E402
+from boolsi_amd.attract import merge_tables, table_from_merged  # noqa: E402
+from boolsi_amd.compile import compile_problem  # noqa: E402
+from boolsi_amd.constants import Mode  # noqa: E402
+from boolsi_amd.dist import Comm, partition  # noqa: E402
+from boolsi_amd.input import parse_input_text  # noqa: E402
+from oracle.cpu_oracle import Oracle  # noqa: E402   (stands in for the GPU engine on CPU-only hosts)
+
+
+def main():
+    out_path = sys.argv[1]
+    comm = Comm.from_env(backend='gloo')
+    cfg = parse_input_text(synth.config3_yaml(), 4096, Mode.ATTRACT)
+    net, space = compile_problem(cfg)
+    n_total = 20000 + 13                      # ragged on purpose
+    first, count = partition(n_total, comm.world, comm.rank)
+    _, table, none, steps = Oracle(net, space).attract(1000 + first, count, 4096)
+    mine = np.zeros(len(table), _lib.ATTR_REC)
+    for name in ('key', 'length', 'count', 'sum_l', 'sum_l2_lo', 'sum_l2_hi'):
+        mine[name] = table[name]
+    gathered = comm.allgather_records(table_from_merged(merge_tables([mine]), _lib.ATTR_REC))
+    merged = merge_tables(gathered)
+    none_all, steps_all = comm.allreduce_sum_int([none, steps])
+    slowest = comm.allreduce_max(float(comm.rank))
+    comm.barrier()
+    with open('{}.{}'.format(out_path, comm.rank), 'w') as f:
+        json.dump({'rank': comm.rank, 'world': comm.world, 'first': first, 'count': count,
+                   'merged': {str(k): v for k, v in merged.items()}, 'none': none_all, 'steps': steps_all,
+                   'slowest': slowest, 'per_rank_counts': [len(g) for g in gathered]}, f)
+    comm.shutdown()
+
+
+if __name__ == '__main__':
+    main()
