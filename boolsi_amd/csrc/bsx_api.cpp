@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -62,7 +63,15 @@ struct bsx_engine {
     uint32_t n_nodes = 0, w64 = 0;
     DevNet net{};
     bool lut_in_lds = false;
-    size_t shmem = 0;
+    size_t shmem = 0;           // masks (+ LUT) : target / simulate kernels
+    size_t shmem_attract = 0;   // + LDS mirror of the cycle-state cache
+
+    // cycle-state cache (valid for the current network + origin fixed nodes)
+    bool cache_enabled = true;
+    uint32_t cache_lds_slots = 0;
+    DevBuf<CycleRecord> d_cc_journal;
+    DevBuf<unsigned int> d_cc_claims;
+    DevBuf<unsigned int> d_cc_count;
     DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
 
     // problem space
@@ -134,6 +143,14 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
         (e = h->d_ctr.alloc(1)) != hipSuccess) {
         g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
+        delete h;
+        return BSX_ERR_HIP;
+    }
+    const char* cc_env = std::getenv("BSX_CYCLE_CACHE");       // "0" disables the cycle-state cache (A/B runs, tests)
+    h->cache_enabled = !(cc_env && cc_env[0] == '0');
+    if ((e = h->d_cc_journal.alloc(kCycleJournalCap)) != hipSuccess ||
+        (e = h->d_cc_claims.alloc(kCycleClaimSlots)) != hipSuccess || (e = h->d_cc_count.alloc(1)) != hipSuccess) {
+        g_create_error = std::string("cycle cache allocation: ") + hipGetErrorString(e);
         delete h;
         return BSX_ERR_HIP;
     }
@@ -249,12 +266,19 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     h->net.wide_preds = h->d_wide_preds.p;
     h->net.wide_tt = h->d_wide_tt.p;
 
-    // LDS budget: masks (+pad) [+ LUT].  Keep the LUT in LDS while a workgroup fits in 144 KiB.
+    // LDS budget: masks (+pad) [+ LUT] [+ cycle-cache mirror].  Keep the LUT in LDS while a
+    // workgroup fits in 144 KiB.
     const size_t mask_bytes = (((size_t)(1u << k_mux) * nw + 3) & ~size_t(3)) * 4;
     const size_t lut_bytes = lut.size() * 4;
-    h->lut_in_lds = mask_bytes + lut_bytes + 64 <= 144 * 1024;
+    const size_t cache_stride = ((2 * nw + 2 + 3) & ~3u) * 4;
+    uint32_t slots = 1;
+    while ((size_t)slots * 2 * cache_stride <= kCycleCacheLdsBytes) slots *= 2;
+    h->cache_lds_slots = slots;
+    const size_t cache_bytes = (size_t)slots * cache_stride + 16 + 16;     // + header + alignment
+    h->lut_in_lds = mask_bytes + lut_bytes + cache_bytes + 64 <= 144 * 1024;
     h->shmem = mask_bytes + (h->lut_in_lds ? lut_bytes : 0) + 64;
-    HIPCHK(h, configure_kernels((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
+    h->shmem_attract = h->shmem + cache_bytes;
+    HIPCHK(h, configure_kernels((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract));
     h->have_net = true;
     return BSX_OK;
 }
@@ -321,6 +345,10 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, h->d_pv.upload(pv));
     HIPCHK(h, h->d_set.upload(set));
     HIPCHK(h, h->d_clr.upload(clr));
+    // cycles depend on the network and the origin fixed nodes: start the cache empty
+    HIPCHK(h, hipMemset(h->d_cc_journal.p, 0, sizeof(CycleRecord) * kCycleJournalCap));
+    HIPCHK(h, hipMemset(h->d_cc_claims.p, 0, sizeof(unsigned int) * kCycleClaimSlots));
+    HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     sp.n_any = n_any;
     sp.identity_any = identity ? 1 : 0;
     sp.n_fv = n_fixed_var;
@@ -344,9 +372,9 @@ struct Launch {
     uint32_t chunk;
 };
 
-Launch plan_persistent(const bsx_engine* h, uint64_t count) {
+Launch plan_persistent(const bsx_engine* h, uint64_t count, size_t shmem) {
     const uint32_t cus = (uint32_t)h->prop.multiProcessorCount;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(h->shmem, 1));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(shmem, 1));
     per_cu = std::max(1u, std::min(per_cu, 4u));
     uint64_t blocks = (uint64_t)cus * per_cu;
     const uint64_t need = (count + kBlock - 1) / kBlock;
@@ -398,7 +426,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     if (count == 0) return BSX_OK;
     if (max_t != BSX_T_INF && max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
 
-    const Launch L = plan_persistent(h, count);
+    const Launch L = plan_persistent(h, count, h->shmem_attract);
     const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
     const uint64_t log_cap = waves * kTableSlots + (1u << 16);
     DevBuf<LogRec> d_log;
@@ -419,10 +447,16 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     P.log = d_log.p;
     P.log_cap = log_cap;
     P.per_problem = per_problem ? d_pp.p : nullptr;
+    P.cc.journal = h->d_cc_journal.p;
+    P.cc.journal_count = h->d_cc_count.p;
+    P.cc.claims = h->d_cc_claims.p;
+    // cycles depend on the fixed nodes: with fixed-node variations they differ per problem
+    P.cc.enabled = (h->cache_enabled && h->sp.n_fv == 0) ? 1u : 0u;
+    P.cc.lds_slots = h->cache_lds_slots;
 
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem, h->stream, P));
+    HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem_attract, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     Counters ctr{};
     HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
@@ -495,7 +529,7 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
 
-    const Launch L = plan_persistent(h, count);
+    const Launch L = plan_persistent(h, count, h->shmem);
     DevBuf<HitRec> d_hits;
     HIPCHK(h, d_hits.alloc(std::min<uint64_t>(cap, count)));
     TargetParams P{};

@@ -77,6 +77,33 @@ struct Counters {               // zeroed before every launch
     unsigned int step_limit_hits;
 };
 
+// Cache of known cycle states (DESIGN.md "cycle-state cache").  A trajectory enters its attractor at
+// time T_p + mu, which is the first time its state is a cycle state; once ALL states of an attractor
+// are known, a lookup per step ends the search there (mu steps) instead of running Brent's detector
+// and the mu pass (about 2.5 x (mu + lambda) steps).  The first lane to find an attractor appends
+// (key, length) to a journal in HBM; every workgroup regenerates the cycle from the key and mirrors
+// its states into LDS, making them visible all at once (a partially visible cycle would let a
+// trajectory slip past its entry point and report a larger mu).  The cache never changes a result.
+constexpr uint32_t kCycleCacheMaxLen = 64;        // longer cycles are not cached
+constexpr uint32_t kCycleCacheLdsBytes = 16 * 1024;
+constexpr uint32_t kCycleJournalCap = 4096;       // attractors
+constexpr uint32_t kCycleClaimSlots = 8192;       // fingerprints of published keys (dedupe)
+
+struct CycleRecord {
+    uint32_t key[kMaxW32];
+    uint32_t length;
+    uint32_t ready;             // written last (release)
+};
+static_assert(sizeof(CycleRecord) == 40, "CycleRecord layout");
+
+struct CycleCache {
+    CycleRecord* journal;
+    unsigned int* journal_count;
+    unsigned int* claims;       // kCycleClaimSlots fingerprints, 0 = free
+    uint32_t enabled;
+    uint32_t lds_slots;         // power of two; the LDS mirror holds at most lds_slots / 2 states
+};
+
 struct AttractParams {
     DevNet net;
     DevSpace sp;
@@ -89,6 +116,7 @@ struct AttractParams {
     LogRec* log;
     uint64_t log_cap;
     ProblemRec32* per_problem;  // nullable
+    CycleCache cc;
 };
 
 struct HitRec { uint64_t offset; uint64_t t; };

@@ -406,9 +406,9 @@ __device__ __forceinline__ void table_merge(const AttractParams& P, TableSlot<NW
 enum Phase : uint32_t { PH_IDLE = 0, PH_DONE = 1, PH_WARM = 2, PH_BRENT = 3, PH_ADVANCE = 4, PH_MU = 5 };
 
 // Results are recorded and free lanes refilled in "service rounds", entered when at least this many
-// lanes of the wave are waiting.  Enumeration (index -> problem) and aggregation are ~5x the cost of
-// a network update, so they are run for several lanes at once instead of whenever one lane finishes.
-constexpr uint32_t kServiceLanes = 8;
+// lanes of the wave are waiting.  Enumeration (index -> problem) and aggregation cost several network
+// updates, so they are run for many lanes at once instead of whenever one lane finishes.
+constexpr uint32_t kServiceLanes = 12;
 
 // Wave-level dequeue of problem offsets.
 struct WaveQueue {
@@ -423,6 +423,157 @@ __device__ __forceinline__ uint64_t grab_chunk(unsigned long long* cursor, uint3
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cycle-state cache (bsx_device.h).  LDS mirror entry: [state NW][tag][length][key NW] padded to a
+// multiple of 4 words, so the probe of a lookup is one aligned 16-byte read for NW <= 2.
+template <int NW>
+struct CacheLayout {
+    static constexpr int kStride = ((2 * NW + 2) + 3) & ~3;
+};
+
+template <int NW>
+__device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]) {
+    uint32_t h = s[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        constexpr int kRot[8] = {0, 5, 10, 15, 20, 25, 3, 8};      // all in 1..31: no out-of-range shift
+        h ^= (s[w] << kRot[w]) | (s[w] >> (32 - kRot[w]));
+    }
+    h ^= h >> 16;
+    h ^= h >> 8;
+    return h;
+}
+
+// LDS mirror: word 0 of the header = number of attractors whose states are all inserted ("visible");
+// an entry's tag is the 1-based sequence number of its attractor and counts only when <= visible.
+constexpr int kCacheHeaderWords = 4;
+
+template <int NW>
+__device__ __forceinline__ bool cache_lookup(const uint32_t* lc, uint32_t mask, uint32_t visible,
+                                             const uint32_t (&s)[NW], uint32_t& length, uint32_t (&key)[NW]) {
+    constexpr int S = CacheLayout<NW>::kStride;
+    const uint32_t* base = lc + kCacheHeaderWords;
+    uint32_t h = hash_state<NW>(s) & mask;
+    for (;;) {      // the table is at most half full, so the walk ends at an empty tag
+        const uint32_t* e = base + h * S;
+        if constexpr (NW == 1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+            if (v.y == 0) return false;
+            if (v.x == s[0] && v.y <= visible) { length = v.z; key[0] = v.w; return true; }
+        } else if constexpr (NW == 2) {
+            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+            if (v.z == 0) return false;
+            if (v.x == s[0] && v.y == s[1] && v.z <= visible) {
+                const uint2 k = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(e + 4, 8));
+                length = v.w; key[0] = k.x; key[1] = k.y;
+                return true;
+            }
+        } else {
+            uint32_t head[NW + 2];
+#pragma unroll
+            for (int i = 0; i < NW + 2; ++i) head[i] = e[i];
+            if (head[NW] == 0) return false;
+            bool same = head[NW] <= visible;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) same = same && head[w] == s[w];
+            if (same) {
+                length = head[NW + 1];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) key[w] = e[NW + 2 + w];
+                return true;
+            }
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t cache_visible(const uint32_t* lc) {
+    return __hip_atomic_load(lc, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Single-thread insert into the LDS mirror (only thread 0 of a workgroup writes it).
+template <int NW>
+__device__ __forceinline__ void cache_insert_lds(uint32_t* lc, uint32_t mask, const uint32_t (&s)[NW],
+                                                 uint32_t length, const uint32_t (&key)[NW], uint32_t tag) {
+    constexpr int S = CacheLayout<NW>::kStride;
+    uint32_t* base = lc + kCacheHeaderWords;
+    uint32_t h = hash_state<NW>(s) & mask;
+    while (base[h * S + NW] != 0) h = (h + 1) & mask;
+    uint32_t* e = base + h * S;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { e[w] = s[w]; e[NW + 2 + w] = key[w]; }
+    e[NW + 1] = length;
+    e[NW] = tag;
+}
+
+// Thread 0: take the attractors published since `seen` (by any workgroup) from the HBM journal,
+// regenerate their cycles from the key and make each cycle visible in the LDS mirror at once.
+template <int NW, int K>
+__device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<NW, K>& nv,
+                                           const uint32_t (&fm)[NW], const uint32_t (&fv)[NW], uint32_t* lc,
+                                           uint32_t& seen, uint32_t& n_states, uint32_t& n_attr) {
+    const uint32_t mask = cc.lds_slots - 1;
+    uint32_t jc = __hip_atomic_load(cc.journal_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (jc > kCycleJournalCap) jc = kCycleJournalCap;
+    while (seen < jc) {
+        const CycleRecord* r = &cc.journal[seen];
+        if (__hip_atomic_load(&r->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) break;   // next time
+        uint32_t key[NW], s[NW], nxt[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) key[w] = __hip_atomic_load(&r->key[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t len = __hip_atomic_load(&r->length, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++seen;
+        uint32_t l2, k2[NW];
+        if (cache_lookup<NW>(lc, mask, n_attr, key, l2, k2)) continue;              // duplicate record
+        if (len == 0 || len > kCycleCacheMaxLen || n_states + len > cc.lds_slots / 2) continue;   // does not fit
+        const uint32_t tag = n_attr + 1;
+        copy_words<NW>(s, key);
+        for (uint32_t i = 0; i < len; ++i) {
+            cache_insert_lds<NW>(lc, mask, s, len, key, tag);
+            net_step<NW, K>(nv, s, fm, fv, nxt);
+            copy_words<NW>(s, nxt);
+        }
+        n_states += len;
+        n_attr = tag;
+        __hip_atomic_store(lc, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// Append (key, length) to the journal unless its fingerprint has been claimed already.  Rare path.
+template <int NW>
+__device__ __forceinline__ void cache_publish(const CycleCache& cc, const uint32_t (&key)[NW], uint32_t length) {
+    uint32_t fp = hash_state<NW>(key) * 0x9E3779B1u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) fp = (fp ^ key[w]) * 0x85EBCA6Bu;
+    fp |= 1u;                                                      // never 0
+    uint32_t h = (fp >> 7) & (kCycleClaimSlots - 1);
+    for (int probe = 0; probe < 32; ++probe) {
+        const unsigned int was = atomicCAS(&cc.claims[h], 0u, fp);
+        if (was == fp) return;                                     // published (or being published) already
+        if (was == 0u) {
+            const unsigned int j = atomicAdd(cc.journal_count, 1u);
+            if (j >= kCycleJournalCap) return;
+            CycleRecord* r = &cc.journal[j];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) __hip_atomic_store(&r->key[w], key[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&r->length, length, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&r->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        h = (h + 1) & (kCycleClaimSlots - 1);
+    }
+}
+
+// Enumeration fast path: no variations, 'any' nodes = nodes 0..n_any-1 with n_any <= 64.
+template <int NW>
+__device__ __forceinline__ void init_problem_simple(const DevSpace& sp, uint64_t p, uint32_t (&s)[NW]) {
+    const uint64_t d = sp.first_digits[0] + p;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s[w] = sp.origin[w];
+    s[0] |= (uint32_t)d;
+    if constexpr (NW > 1) s[1] |= (uint32_t)(d >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------
 // attract: attract.py:262-302 semantics (S5-S7, S9, S10) for problems [first, first + count).
 template <int NW, int K, bool LDS_LUT>
 __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
@@ -430,19 +581,43 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
     uint32_t* smem_free;
     const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
-    const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;      // wave-uniform
+    const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
+    const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
+    const bool use_cache = P.cc.enabled != 0;
+    const uint32_t cmask = P.cc.lds_slots - 1;
+
+    // LDS mirror of the cycle-state cache
+    uint32_t* lc = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(smem_free) + 15) & ~uintptr_t(15));
+    uint32_t cc_seen = 0, cc_states = 0, cc_attr = 0, cc_rounds = 0;       // meaningful in thread 0 only
+    uint32_t fm0[NW], fv0[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; }
+    if (use_cache) {
+        for (uint32_t i = threadIdx.x; i < kCacheHeaderWords + P.cc.lds_slots * CacheLayout<NW>::kStride; i += blockDim.x)
+            lc[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
+        __syncthreads();
+    }
+
     TableSlot<NW> slot;
 #pragma unroll
     for (int w = 0; w < NW; ++w) slot.key[w] = 0;
     slot.length = 0; slot.count = 0; slot.sum_l = 0; slot.sum_l2 = 0;
 
+    // A: hare / second pointer, B: tortoise / first pointer, C: min code since the tortoise moved,
+    // D: s(T_p) until the cycle closes, then the attractor key.
     uint32_t A[NW], B[NW], C[NW], D[NW], fm[NW], fv[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { A[w] = B[w] = C[w] = D[w] = 0; fm[w] = fv[w] = 0; }
+    for (int w = 0; w < NW; ++w) { A[w] = B[w] = C[w] = D[w] = 0; fm[w] = P.sp.fixmask[w]; fv[w] = P.sp.fixval[w]; }
     // t: steps since T_p (Brent) / absolute time (warm-up); cnt: pointer advance / mu; sub: which
-    // pointer moves next in PH_MU, and the found flag while in PH_DONE
-    uint32_t phase = PH_IDLE, t = 0, tp = 0, lam = 0, power = 1, cnt = 0, sub = 0;
+    // pointer moves next in PH_MU, the found flag in PH_DONE; pub: result came from the detector
+    uint32_t phase = PH_IDLE, t = 0, tp = P.sp.tp_origin, lam = 0, power = 1, cnt = 0, sub = 0, pub = 0;
     uint32_t brent_limit = 0, cap_rel = 0, exec32 = 0;
+    // vis: number of cached attractors that were completely visible when this lane's detection
+    // started.  Only those may end the search: a cycle that becomes visible while the lane is already
+    // walking on it would be hit at a later state than the entry point (mu too large).
+    uint32_t vis = 0;
     uint64_t pv_digits = 0, my_p = 0;
 
     uint32_t ck[NW];
@@ -466,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                              (work_left && (n_wait >= kServiceLanes || n_run == 0));
         if (service) {
             // ---- resolved problems: statistics, per-problem record, aggregation
-            bool flush = false;
+            bool flush = false, want_pub = false;
             uint32_t fk[NW], flen = 0, fcnt = 0;
             uint64_t fsl = 0, fsl2 = 0;
 #pragma unroll
@@ -479,25 +654,42 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                 // reference loop stops at T_p + mu + lambda when found, at max_t otherwise (model.py:201)
                 steps_ref += found ? traj_l + lam : (P.cap_rel_inf ? 0ull : P.max_t);
                 const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
+                want_pub = found && pub && use_cache && lam <= kCycleCacheMaxLen;
                 if (P.per_problem) {
                     ProblemRec32 r;
 #pragma unroll
                     for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
                     if (keep) {
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) r.key[w] = C[w];
+                        for (int w = 0; w < NW; ++w) r.key[w] = D[w];
                     }
                     r.length = keep ? lam : 0; r.trajectory_l = keep ? (uint32_t)traj_l : 0; r.found = keep; r.pad = 0;
                     P.per_problem[my_p] = r;
                 }
                 if (!keep) ++n_none;
-                else if (ccnt && eq_words<NW>(ck, C) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += traj_l * traj_l; }
+                else if (ccnt && eq_words<NW>(ck, D) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += traj_l * traj_l; }
                 else {
                     if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
-                    copy_words<NW>(ck, C); clen = lam; ccnt = 1; csl = traj_l; csl2 = traj_l * traj_l;
+                    copy_words<NW>(ck, D); clen = lam; ccnt = 1; csl = traj_l; csl2 = traj_l * traj_l;
                 }
             }
             if (__ballot(flush)) table_merge<NW>(P, slot, lane, flush, fk, flen, fcnt, fsl, fsl2);
+
+            // ---- cycle-state cache upkeep (rare): pull what others published; one lane per new
+            //      attractor walks its cycle once more to publish the states
+            if (use_cache) {
+                if (threadIdx.x == 0 && (++cc_rounds & 31u) == 0)
+                    cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
+                uint64_t cand = __ballot(want_pub);
+                while (cand) {
+                    const int src = __builtin_ctzll(cand);
+                    uint32_t k[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) k[w] = __builtin_amdgcn_readlane(D[w], src);
+                    cand &= ~__ballot(want_pub && eq_words<NW>(D, k));
+                    if (lane == src) cache_publish<NW>(P.cc, D, lam);
+                }
+            }
 
             // ---- refill idle lanes with the next problems of the wave's chunk
             if (work_left) {
@@ -511,11 +703,16 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                 if (avail && idle) {
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (phase == PH_IDLE && rank < avail) {
-                        Problem<NW> pr;
                         my_p = q.next + rank;
-                        init_problem<NW>(P.sp, my_p, pr);
-                        copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
-                        pv_digits = pr.pv_digits; tp = pr.tp; t = 0; exec32 = 0;
+                        if (simple_space) {
+                            init_problem_simple<NW>(P.sp, my_p, A);
+                        } else {
+                            Problem<NW> pr;
+                            init_problem<NW>(P.sp, my_p, pr);
+                            copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
+                            pv_digits = pr.pv_digits; tp = pr.tp;
+                        }
+                        t = 0; exec32 = 0; pub = 0;
                         // found iff mu + lambda <= max_t - T_p (S7); Brent needs at most 3x that many steps
                         if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
                         else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
@@ -523,6 +720,7 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                         else {
                             phase = PH_BRENT; lam = 0; power = 1;
                             copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+                            vis = use_cache ? cache_visible(lc) : 0u;
                         }
                     }
                     const uint64_t n_idle = (uint64_t)__popcll(idle);
@@ -530,6 +728,18 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                 }
             }
             continue;       // re-evaluate the wave state (nothing to step if every lane is idle)
+        }
+
+        // ---- known cycle state?  Then the trajectory has just entered its attractor: mu = t.
+        if (use_cache && phase == PH_BRENT) {
+            uint32_t l2, k2[NW];
+            if (cache_lookup<NW>(lc, cmask, vis, A, l2, k2)) {
+                phase = PH_DONE; pub = 0;
+                sub = (t <= cap_rel && l2 <= cap_rel - t) ? 1u : 0u;        // mu + lambda <= max_t - T_p
+                cnt = sub ? t : 0u;
+                lam = l2;
+                copy_words<NW>(D, k2);
+            }
         }
 
         // ---- one network update per lane per iteration
@@ -540,47 +750,61 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
         net_step<NW, K>(nv, cur, fm, fv, nxt);
         exec32 += (phase >= PH_WARM) ? 1u : 0u;
 
-        if (has_warmup && phase == PH_WARM) {
-            ++t;
-            apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
-            copy_words<NW>(A, nxt);
-            if (t == tp) {
-                phase = PH_BRENT; lam = 0; power = 1; t = 0;
-                copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+        if (phase == PH_BRENT) {
+            // Brent's detector, written without nested branches (every value is a select)
+            const uint32_t t1 = t + 1, lam1 = lam + 1;
+            const bool e = eq_words<NW>(nxt, B);                    // hare met the tortoise: cycle closed
+            const bool tele = !e && lam1 == power;                  // tortoise jumps to the hare
+            const bool lower = tele || lt_words<NW>(nxt, C);
+            const bool over = !e && t1 >= brent_limit;
+            const bool too_long = e && lam1 > cap_rel;              // lambda alone exceeds max_t - T_p
+            const bool go = e && !too_long;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t key_w = C[w];                        // min code over the cycle when e
+                C[w] = lower ? nxt[w] : C[w];
+                A[w] = go ? D[w] : nxt[w];
+                B[w] = go ? D[w] : (tele ? nxt[w] : B[w]);
+                D[w] = go ? key_w : D[w];
             }
-        } else if (phase == PH_BRENT) {
-            ++t; ++lam;
-            copy_words<NW>(A, nxt);
-            if (eq_words<NW>(A, B)) {
-                // cycle closed: lam = attractor length, C = min code seen since the tortoise moved = key
-                if (lam > cap_rel) { phase = PH_DONE; sub = 0; cnt = 0; }   // lambda alone exceeds max_t - T_p
-                else { phase = PH_ADVANCE; cnt = 0; copy_words<NW>(A, D); copy_words<NW>(B, D); }
-            } else {
-                if (lt_words<NW>(A, C)) copy_words<NW>(C, A);
-                if (lam == power) { copy_words<NW>(B, A); copy_words<NW>(C, A); power <<= 1; lam = 0; }
-                if (t >= brent_limit) {
-                    phase = PH_DONE; sub = 0; cnt = 0;
-                    if (cap_rel == 0xFFFFFFFFu) ++limit_hits;
+            power = tele ? power << 1 : power;
+            lam = tele ? 0u : lam1;                                 // = lambda when e
+            t = t1;
+            cnt = 0;
+            sub = 0;
+            pub = go ? 1u : pub;
+            limit_hits += (over && cap_rel == 0xFFFFFFFFu) ? 1u : 0u;
+            phase = go ? PH_ADVANCE : ((over || too_long) ? PH_DONE : PH_BRENT);
+        } else if (phase >= PH_WARM) {
+            // rare phases: warm-up under perturbations, the mu pass after a detection, cache publishing
+            if (has_warmup && phase == PH_WARM) {
+                ++t;
+                apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
+                copy_words<NW>(A, nxt);
+                if (t == tp) {
+                    phase = PH_BRENT; lam = 0; power = 1; t = 0;
+                    copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
+                    vis = use_cache ? cache_visible(lc) : 0u;
                 }
-            }
-        } else if (phase == PH_ADVANCE) {
-            // second pointer y = A moves lambda steps ahead of x = B = s(T_p)
-            ++cnt;
-            copy_words<NW>(A, nxt);
-            if (cnt == lam) {
-                cnt = 0; sub = 0;
-                if (eq_words<NW>(A, B)) { phase = PH_DONE; sub = 1; }                       // mu = 0
-                else if (lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { phase = PH_DONE; }     // mu >= 1: mu + lam > cap
-                else phase = PH_MU;
-            }
-        } else if (phase == PH_MU) {
-            // lagged two-pointer pass, one network update per iteration: y, then x, then compare
-            if (!sub) { copy_words<NW>(A, nxt); sub = 1; }
-            else {
-                copy_words<NW>(B, nxt); ++cnt;
-                if (eq_words<NW>(A, B)) { phase = PH_DONE; sub = 1; }                       // mu = cnt
-                else if (cnt + lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { phase = PH_DONE; sub = 0; cnt = 0; }
-                else sub = 0;
+            } else if (phase == PH_ADVANCE) {
+                // second pointer y = A moves lambda steps ahead of x = B = s(T_p)
+                ++cnt;
+                copy_words<NW>(A, nxt);
+                if (cnt == lam) {
+                    cnt = 0; sub = 0;
+                    if (eq_words<NW>(A, B)) { phase = PH_DONE; sub = 1; }                       // mu = 0
+                    else if (lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { phase = PH_DONE; }     // mu >= 1: mu + lam > cap
+                    else phase = PH_MU;
+                }
+            } else if (phase == PH_MU) {
+                // lagged two-pointer pass, one network update per iteration: y, then x, then compare
+                if (!sub) { copy_words<NW>(A, nxt); sub = 1; }
+                else {
+                    copy_words<NW>(B, nxt); ++cnt;
+                    if (eq_words<NW>(A, B)) { phase = PH_DONE; sub = 1; }                       // mu = cnt
+                    else if (cnt + lam >= cap_rel && cap_rel != 0xFFFFFFFFu) { phase = PH_DONE; sub = 0; cnt = 0; }
+                    else sub = 0;
+                }
             }
         }
     }

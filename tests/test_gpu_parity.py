@@ -24,10 +24,14 @@ from util import load, t_of, compile_case, contiguous_runs, GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def eng():
+@pytest.fixture(scope='module', params=['cycle_cache', 'no_cycle_cache'])
+def eng(request):
+    """Every test runs twice: with the cycle-state cache (trajectories end at mu on a cached cycle
+    state) and without it (every trajectory runs Brent's detector + the mu pass)."""
     from boolsi_amd.engine import Engine
+    os.environ['BSX_CYCLE_CACHE'] = '1' if request.param == 'cycle_cache' else '0'
     e = Engine(0)
+    os.environ.pop('BSX_CYCLE_CACHE')
     yield e
     e.close()
 
