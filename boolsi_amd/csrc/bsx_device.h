@@ -5,7 +5,7 @@
 namespace bsx {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;                 // 4 waves per workgroup
+constexpr int kBlock = 512;                 // 8 waves per workgroup share one LUT + cache mirror in LDS
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxW32 = 8;                  // 32-bit words per state (n <= 256)
 constexpr int kMaxMuxK = 6;                 // nodes with more predecessors take the "wide" path

@@ -403,7 +403,7 @@ __device__ __forceinline__ void table_merge(const AttractParams& P, TableSlot<NW
 }
 
 // Lane phases.  PH_DONE = result computed, waiting for the wave's next service round.
-enum Phase : uint32_t { PH_IDLE = 0, PH_DONE = 1, PH_WARM = 2, PH_BRENT = 3, PH_ADVANCE = 4, PH_MU = 5 };
+enum Phase : uint32_t { PH_IDLE = 0, PH_DONE = 1, PH_WARM = 2, PH_FAST = 3, PH_BRENT = 4, PH_ADVANCE = 5, PH_MU = 6 };
 
 // Results are recorded and free lanes refilled in "service rounds", entered when at least this many
 // lanes of the wave are waiting.  Enumeration (index -> problem) and aggregation cost several network
@@ -575,8 +575,15 @@ __device__ __forceinline__ void init_problem_simple(const DevSpace& sp, uint64_t
 
 // ------------------------------------------------------------------------------------------------
 // attract: attract.py:262-302 semantics (S5-S7, S9, S10) for problems [first, first + count).
+//
+// Lane life cycle: IDLE -> [WARM: T_p steps under perturbations] -> FAST: step + cycle-cache lookup
+// only (taken when cached attractors exist; ends at mu on the first cached cycle state) -> if nothing
+// is hit within kFastSteps the search restarts from s(T_p) in BRENT (detector + lookups) -> ADVANCE ->
+// MU -> DONE.  With a warm cache almost every lane ends in FAST, which carries no detector state.
+constexpr uint32_t kFastSteps = 48;
+
 template <int NW, int K, bool LDS_LUT>
-__global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
+__global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
     const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
@@ -605,18 +612,22 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
     for (int w = 0; w < NW; ++w) slot.key[w] = 0;
     slot.length = 0; slot.count = 0; slot.sum_l = 0; slot.sum_l2 = 0;
 
-    // A: hare / second pointer, B: tortoise / first pointer, C: min code since the tortoise moved,
-    // D: s(T_p) until the cycle closes, then the attractor key.
+    // A: current state / hare / second pointer, B: tortoise / first pointer, C: min code since the
+    // tortoise moved, D: s(T_p) until the cycle closes or a cached state is hit, then the attractor key.
     uint32_t A[NW], B[NW], C[NW], D[NW], fm[NW], fv[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { A[w] = B[w] = C[w] = D[w] = 0; fm[w] = P.sp.fixmask[w]; fv[w] = P.sp.fixval[w]; }
-    // t: steps since T_p (Brent) / absolute time (warm-up); cnt: pointer advance / mu; sub: which
-    // pointer moves next in PH_MU, the found flag in PH_DONE; pub: result came from the detector
+    for (int w = 0; w < NW; ++w) { A[w] = B[w] = C[w] = D[w] = 0; fm[w] = fm0[w]; fv[w] = fv0[w]; }
+    // t: steps since T_p (absolute time during warm-up); cnt: pointer advance / mu; sub: which pointer
+    // moves next in PH_MU, the found flag in PH_DONE; pub: the result came from the detector
     uint32_t phase = PH_IDLE, t = 0, tp = P.sp.tp_origin, lam = 0, power = 1, cnt = 0, sub = 0, pub = 0;
-    uint32_t brent_limit = 0, cap_rel = 0, exec32 = 0;
-    // vis: number of cached attractors that were completely visible when this lane's detection
-    // started.  Only those may end the search: a cycle that becomes visible while the lane is already
-    // walking on it would be hit at a later state than the entry point (mu too large).
+    uint32_t exec32 = 0;
+    // found iff mu + lambda <= max_t - T_p (S7); Brent needs at most 3x that many steps
+    uint32_t cap_rel, brent_limit;
+    if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
+    else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
+    // vis: number of cached attractors that were completely visible when this lane's search started.
+    // Only those may end it: a cycle that becomes visible while the lane is already walking on it
+    // would be hit at a later state than the entry point (mu too large).
     uint32_t vis = 0;
     uint64_t pv_digits = 0, my_p = 0;
 
@@ -630,6 +641,23 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
     uint32_t n_none = 0, limit_hits = 0;
 
     WaveQueue q{0, 0, true};
+
+    // start of the search at s(T_p) = A: snapshot the cache, look s(T_p) itself up, pick the mode
+    auto begin_search = [&]() {
+        copy_words<NW>(D, A);
+        t = 0; pub = 0;
+        vis = use_cache ? cache_visible(lc) : 0u;
+        uint32_t l2 = 0, k2[NW];
+        if (vis && cache_lookup<NW>(lc, cmask, vis, A, l2, k2)) {
+            phase = PH_DONE; lam = l2; cnt = 0; sub = (l2 <= cap_rel) ? 1u : 0u;     // mu = 0
+            copy_words<NW>(D, k2);
+        } else if (vis) {
+            phase = PH_FAST;
+        } else {
+            phase = PH_BRENT; lam = 0; power = 1;
+            copy_words<NW>(B, A); copy_words<NW>(C, A);
+        }
+    };
 
     for (;;) {
         const uint32_t n_run = __popcll(__ballot(phase >= PH_WARM));
@@ -649,10 +677,11 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
             if (phase == PH_DONE) {
                 phase = PH_IDLE;
                 const bool found = sub != 0;
-                const uint64_t traj_l = (uint64_t)tp + cnt;
+                const uint32_t traj32 = tp + cnt;
+                const uint64_t traj_l = traj32;
                 steps_exec += exec32;
                 // reference loop stops at T_p + mu + lambda when found, at max_t otherwise (model.py:201)
-                steps_ref += found ? traj_l + lam : (P.cap_rel_inf ? 0ull : P.max_t);
+                steps_ref += found ? (uint64_t)(traj32 + lam) : (P.cap_rel_inf ? 0ull : P.max_t);
                 const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
                 want_pub = found && pub && use_cache && lam <= kCycleCacheMaxLen;
                 if (P.per_problem) {
@@ -663,20 +692,21 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
 #pragma unroll
                         for (int w = 0; w < NW; ++w) r.key[w] = D[w];
                     }
-                    r.length = keep ? lam : 0; r.trajectory_l = keep ? (uint32_t)traj_l : 0; r.found = keep; r.pad = 0;
+                    r.length = keep ? lam : 0; r.trajectory_l = keep ? traj32 : 0; r.found = keep; r.pad = 0;
                     P.per_problem[my_p] = r;
                 }
+                const uint64_t sq = (uint64_t)traj32 * traj32;
                 if (!keep) ++n_none;
-                else if (ccnt && eq_words<NW>(ck, D) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += traj_l * traj_l; }
+                else if (ccnt && eq_words<NW>(ck, D) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += sq; }
                 else {
                     if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
-                    copy_words<NW>(ck, D); clen = lam; ccnt = 1; csl = traj_l; csl2 = traj_l * traj_l;
+                    copy_words<NW>(ck, D); clen = lam; ccnt = 1; csl = traj_l; csl2 = sq;
                 }
             }
             if (__ballot(flush)) table_merge<NW>(P, slot, lane, flush, fk, flen, fcnt, fsl, fsl2);
 
-            // ---- cycle-state cache upkeep (rare): pull what others published; one lane per new
-            //      attractor walks its cycle once more to publish the states
+            // ---- cycle-state cache upkeep (rare): pull what others published; one lane per newly
+            //      detected attractor appends it to the journal
             if (use_cache) {
                 if (threadIdx.x == 0 && (++cc_rounds & 31u) == 0)
                     cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
@@ -704,6 +734,7 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (phase == PH_IDLE && rank < avail) {
                         my_p = q.next + rank;
+                        exec32 = 0;
                         if (simple_space) {
                             init_problem_simple<NW>(P.sp, my_p, A);
                         } else {
@@ -711,35 +742,17 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
                             init_problem<NW>(P.sp, my_p, pr);
                             copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
                             pv_digits = pr.pv_digits; tp = pr.tp;
+                            if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
+                            else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
                         }
-                        t = 0; exec32 = 0; pub = 0;
-                        // found iff mu + lambda <= max_t - T_p (S7); Brent needs at most 3x that many steps
-                        if (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) { cap_rel = 0xFFFFFFFFu; brent_limit = kStepLimit; }
-                        else { cap_rel = (uint32_t)(P.max_t - tp); brent_limit = 3u * cap_rel + 2u; }
-                        if (tp > 0) phase = PH_WARM;
-                        else {
-                            phase = PH_BRENT; lam = 0; power = 1;
-                            copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
-                            vis = use_cache ? cache_visible(lc) : 0u;
-                        }
+                        if (has_warmup && tp > 0) { phase = PH_WARM; t = 0; }
+                        else begin_search();
                     }
                     const uint64_t n_idle = (uint64_t)__popcll(idle);
                     q.next += n_idle < avail ? n_idle : avail;
                 }
             }
             continue;       // re-evaluate the wave state (nothing to step if every lane is idle)
-        }
-
-        // ---- known cycle state?  Then the trajectory has just entered its attractor: mu = t.
-        if (use_cache && phase == PH_BRENT) {
-            uint32_t l2, k2[NW];
-            if (cache_lookup<NW>(lc, cmask, vis, A, l2, k2)) {
-                phase = PH_DONE; pub = 0;
-                sub = (t <= cap_rel && l2 <= cap_rel - t) ? 1u : 0u;        // mu + lambda <= max_t - T_p
-                cnt = sub ? t : 0u;
-                lam = l2;
-                copy_words<NW>(D, k2);
-            }
         }
 
         // ---- one network update per lane per iteration
@@ -750,42 +763,63 @@ __global__ __launch_bounds__(kBlock) void k_attract(const AttractParams P) {
         net_step<NW, K>(nv, cur, fm, fv, nxt);
         exec32 += (phase >= PH_WARM) ? 1u : 0u;
 
-        if (phase == PH_BRENT) {
+        // ---- FAST / BRENT: the new state is s(T_p + t + 1); is it a known cycle state?
+        bool hit = false;
+        uint32_t l2 = 0, k2[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k2[w] = 0;
+        if (vis && (phase == PH_FAST || phase == PH_BRENT)) hit = cache_lookup<NW>(lc, cmask, vis, nxt, l2, k2);
+
+        if (phase == PH_FAST) {
+            const uint32_t t1 = t + 1;
+            const bool ok = hit && t1 <= cap_rel && l2 <= cap_rel - t1;         // mu + lambda <= max_t - T_p
+            const bool restart = !hit && t1 >= kFastSteps;                      // not on a cached cycle yet
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                A[w] = restart ? D[w] : nxt[w];
+                B[w] = restart ? D[w] : B[w];
+                C[w] = restart ? D[w] : C[w];
+                D[w] = hit ? k2[w] : D[w];
+            }
+            t = restart ? 0u : t1;
+            lam = hit ? l2 : 0u;
+            power = 1;
+            cnt = ok ? t1 : 0u;
+            sub = ok ? 1u : 0u;
+            phase = hit ? PH_DONE : (restart ? PH_BRENT : PH_FAST);
+        } else if (phase == PH_BRENT) {
             // Brent's detector, written without nested branches (every value is a select)
             const uint32_t t1 = t + 1, lam1 = lam + 1;
-            const bool e = eq_words<NW>(nxt, B);                    // hare met the tortoise: cycle closed
+            const bool e = !hit && eq_words<NW>(nxt, B);            // hare met the tortoise: cycle closed
             const bool tele = !e && lam1 == power;                  // tortoise jumps to the hare
             const bool lower = tele || lt_words<NW>(nxt, C);
-            const bool over = !e && t1 >= brent_limit;
+            const bool over = !e && !hit && t1 >= brent_limit;
             const bool too_long = e && lam1 > cap_rel;              // lambda alone exceeds max_t - T_p
             const bool go = e && !too_long;
+            const bool ok = hit && t1 <= cap_rel && l2 <= cap_rel - t1;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const uint32_t key_w = C[w];                        // min code over the cycle when e
                 C[w] = lower ? nxt[w] : C[w];
                 A[w] = go ? D[w] : nxt[w];
                 B[w] = go ? D[w] : (tele ? nxt[w] : B[w]);
-                D[w] = go ? key_w : D[w];
+                D[w] = hit ? k2[w] : (go ? key_w : D[w]);
             }
             power = tele ? power << 1 : power;
-            lam = tele ? 0u : lam1;                                 // = lambda when e
+            lam = hit ? l2 : (tele ? 0u : lam1);                    // = lambda when e
             t = t1;
-            cnt = 0;
-            sub = 0;
+            cnt = ok ? t1 : 0u;
+            sub = ok ? 1u : 0u;
             pub = go ? 1u : pub;
             limit_hits += (over && cap_rel == 0xFFFFFFFFu) ? 1u : 0u;
-            phase = go ? PH_ADVANCE : ((over || too_long) ? PH_DONE : PH_BRENT);
+            phase = hit ? PH_DONE : (go ? PH_ADVANCE : ((over || too_long) ? PH_DONE : PH_BRENT));
         } else if (phase >= PH_WARM) {
-            // rare phases: warm-up under perturbations, the mu pass after a detection, cache publishing
+            // rare phases: warm-up under perturbations, the mu pass after a detection
             if (has_warmup && phase == PH_WARM) {
                 ++t;
                 apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
                 copy_words<NW>(A, nxt);
-                if (t == tp) {
-                    phase = PH_BRENT; lam = 0; power = 1; t = 0;
-                    copy_words<NW>(B, A); copy_words<NW>(C, A); copy_words<NW>(D, A);
-                    vis = use_cache ? cache_visible(lc) : 0u;
-                }
+                if (t == tp) begin_search();
             } else if (phase == PH_ADVANCE) {
                 // second pointer y = A moves lambda steps ahead of x = B = s(T_p)
                 ++cnt;
