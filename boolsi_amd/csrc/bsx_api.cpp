@@ -18,6 +18,7 @@
 
 namespace bsx {
 hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
+hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
 hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
 hipError_t configure_kernels(int nw, int k, bool lds, size_t shmem);
@@ -68,6 +69,7 @@ struct bsx_engine {
 
     // cycle-state cache (valid for the current network + origin fixed nodes)
     bool cache_enabled = true;
+    bool fast_ok = true;        // cleared when the lean kernel's straggler list overflowed for this space
     uint32_t cache_lds_slots = 0;
     DevBuf<CycleRecord> d_cc_journal;
     DevBuf<unsigned int> d_cc_claims;
@@ -349,6 +351,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_journal.p, 0, sizeof(CycleRecord) * kCycleJournalCap));
     HIPCHK(h, hipMemset(h->d_cc_claims.p, 0, sizeof(unsigned int) * kCycleClaimSlots));
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
+    h->fast_ok = true;
     sp.n_any = n_any;
     sp.identity_any = identity ? 1 : 0;
     sp.n_fv = n_fixed_var;
@@ -411,6 +414,72 @@ struct KeyLess {
 
 }  // namespace
 
+namespace {
+
+constexpr uint64_t kFastMinProblems = 8192;     // below this the general kernel alone is used
+constexpr uint64_t kDiscoveryPrefix = 65536;    // problems run through the detector when no attractor is cached yet
+constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps without a cached cycle state)
+
+using MergedTable = std::map<std::vector<uint32_t>, bsx_attr_rec, KeyLess>;
+
+struct AttractRun {
+    Counters ctr{};
+    float ms = 0.f;
+};
+
+// One k_attract launch (general or fast) + merge of its log into `merged` unless `discard_log`.
+int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec>& d_log, MergedTable* merged,
+                        AttractRun& run) {
+    const Launch L = plan_persistent(h, P.count, h->shmem_attract);
+    P.chunk = L.chunk;
+    const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
+    const uint64_t log_cap = waves * kTableSlots + (1u << 16);
+    if (d_log.n < log_cap) HIPCHK(h, d_log.alloc(log_cap));
+    P.log = d_log.p;
+    P.log_cap = log_cap;
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (fast) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem_attract, h->stream, P));
+    else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem_attract, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
+    if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
+    if (!merged) return BSX_OK;
+    const uint64_t n_log = run.ctr.log_cursor;
+    std::vector<LogRec> log(n_log);
+    if (n_log) HIPCHK(h, hipMemcpy(log.data(), d_log.p, n_log * sizeof(LogRec), hipMemcpyDeviceToHost));
+    // merge by key (attract.py:405-455 write_aggregated_attractors_to_db, exact integers)
+    const uint32_t nw = h->net.nw;
+    for (const LogRec& r : log) {
+        std::vector<uint32_t> key(r.key, r.key + nw);
+        auto it = merged->find(key);
+        if (it == merged->end()) {
+            bsx_attr_rec a{};
+            for (uint32_t w = 0; w < nw; ++w) a.key[w >> 1] |= (uint64_t)r.key[w] << (32 * (w & 1));
+            a.length = r.length;
+            it = merged->emplace(key, a).first;
+        }
+        bsx_attr_rec& a = it->second;
+        a.count += r.count;
+        a.sum_l += r.sum_l;
+        const uint64_t lo = a.sum_l2_lo + r.sum_l2;
+        if (lo < a.sum_l2_lo) ++a.sum_l2_hi;
+        a.sum_l2_lo = lo;
+    }
+    return BSX_OK;
+}
+
+// first + delta for spaces whose initial-state digits fit one word (the fast path's precondition)
+void advance_first(DevSpace& sp, const bsx_index* first, uint64_t delta) {
+    for (int w = 0; w < 4; ++w) sp.first_digits[w] = first->init_digits[w];
+    sp.first_digits[0] += delta;
+    sp.first_variant = first->variant;
+}
+
+}  // namespace
+
 extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                                uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
                                uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats) {
@@ -425,12 +494,9 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
     if (max_t != BSX_T_INF && max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
+    if (count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call");
 
-    const Launch L = plan_persistent(h, count, h->shmem_attract);
-    const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
-    const uint64_t log_cap = waves * kTableSlots + (1u << 16);
     DevBuf<LogRec> d_log;
-    HIPCHK(h, d_log.alloc(log_cap));
     DevBuf<ProblemRec32> d_pp;
     if (per_problem) HIPCHK(h, d_pp.alloc(count));
 
@@ -439,13 +505,10 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     P.sp = h->sp;
     set_first(P.sp, first);
     P.count = count;
-    P.chunk = L.chunk;
     P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
     P.max_t = max_t;
     P.max_len = max_len;
     P.ctr = h->d_ctr.p;
-    P.log = d_log.p;
-    P.log_cap = log_cap;
     P.per_problem = per_problem ? d_pp.p : nullptr;
     P.cc.journal = h->d_cc_journal.p;
     P.cc.journal_count = h->d_cc_count.p;
@@ -453,48 +516,98 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // cycles depend on the fixed nodes: with fixed-node variations they differ per problem
     P.cc.enabled = (h->cache_enabled && h->sp.n_fv == 0) ? 1u : 0u;
     P.cc.lds_slots = h->cache_lds_slots;
+    P.fast_steps = kFastSteps;
 
-    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem_attract, h->stream, P));
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    Counters ctr{};
-    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    MergedTable merged;
+    uint64_t n_none = 0, steps_ref = 0, steps_exec = 0;
+    double kernel_ms = 0.0;
+    uint32_t launches = 0, limit_hits = 0;
+    auto account = [&](const AttractRun& r) {
+        n_none += r.ctr.n_none; steps_ref += r.ctr.steps_ref; steps_exec += r.ctr.steps_exec;
+        kernel_ms += r.ms; ++launches; limit_hits += r.ctr.step_limit_hits;
+    };
 
-    if (ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
-    const uint64_t n_log = ctr.log_cursor;
-    std::vector<LogRec> log(n_log);
-    if (n_log) HIPCHK(h, hipMemcpy(log.data(), d_log.p, n_log * sizeof(LogRec), hipMemcpyDeviceToHost));
-
-    // merge by key (attract.py:405-455 write_aggregated_attractors_to_db, exact integers)
-    std::map<std::vector<uint32_t>, bsx_attr_rec, KeyLess> merged;
-    const uint32_t nw = h->net.nw;
-    for (const LogRec& r : log) {
-        std::vector<uint32_t> key(r.key, r.key + nw);
-        auto it = merged.find(key);
-        if (it == merged.end()) {
-            bsx_attr_rec a{};
-            for (uint32_t w = 0; w < nw; ++w) a.key[w >> 1] |= (uint64_t)r.key[w] << (32 * (w & 1));
-            a.length = r.length;
-            it = merged.emplace(key, a).first;
+    // Fast path: simple enumeration (no variations, 'any' nodes = nodes 0..a-1, a <= 64), no warm-up,
+    // cycle cache on.  [discovery prefix with the detector] -> lean kernel -> stragglers.
+    const bool simple = h->sp.identity_any && h->sp.n_any <= 64 && !h->sp.n_fv && !h->sp.n_pv && !h->sp.tp_origin;
+    bool use_fast = P.cc.enabled && simple && h->fast_ok && count >= kFastMinProblems;
+    uint64_t done = 0;
+    if (use_fast) {
+        unsigned int known = 0;
+        HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+        if (known == 0) {
+            AttractParams Q = P;
+            Q.count = std::min<uint64_t>(count, kDiscoveryPrefix);
+            AttractRun r;
+            if (int rc = launch_attract_pass(h, Q, false, d_log, &merged, r)) return rc;
+            account(r);
+            done = Q.count;
+            HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+            if (known == 0) use_fast = false;           // nothing cacheable was found
         }
-        bsx_attr_rec& a = it->second;
-        a.count += r.count;
-        a.sum_l += r.sum_l;
-        const uint64_t lo = a.sum_l2_lo + r.sum_l2;
-        if (lo < a.sum_l2_lo) ++a.sum_l2_hi;
-        a.sum_l2_lo = lo;
     }
+    if (use_fast && done < count) {
+        const uint64_t rest = count - done;
+        DevBuf<uint32_t> d_strag;
+        const uint64_t strag_cap = rest / 4 + 4096;
+        HIPCHK(h, d_strag.alloc(strag_cap));
+        AttractParams Q = P;
+        advance_first(Q.sp, first, done);
+        Q.count = rest;
+        Q.per_problem = per_problem ? d_pp.p + done : nullptr;
+        Q.stragglers = d_strag.p;
+        Q.stragglers_cap = strag_cap;
+        MergedTable fast_merged;
+        AttractRun r;
+        if (int rc = launch_attract_pass(h, Q, true, d_log, &fast_merged, r)) return rc;
+        if (r.ctr.straggler_overflow) {
+            // the cache does not cover this space: drop the lean pass, remember, use the detector
+            h->fast_ok = false;
+            kernel_ms += r.ms; ++launches;
+            steps_exec += r.ctr.steps_exec;
+        } else {
+            account(r);
+            for (auto& kv : fast_merged) {
+                auto it = merged.find(kv.first);
+                if (it == merged.end()) merged.emplace(kv.first, kv.second);
+                else {
+                    bsx_attr_rec& a = it->second;
+                    a.count += kv.second.count; a.sum_l += kv.second.sum_l;
+                    const uint64_t lo = a.sum_l2_lo + kv.second.sum_l2_lo;
+                    a.sum_l2_hi += kv.second.sum_l2_hi + (lo < a.sum_l2_lo ? 1 : 0);
+                    a.sum_l2_lo = lo;
+                }
+            }
+            if (r.ctr.n_stragglers) {
+                AttractParams S = Q;
+                S.count = r.ctr.n_stragglers;
+                S.offsets = d_strag.p;
+                S.stragglers = nullptr;
+                AttractRun rs;
+                if (int rc = launch_attract_pass(h, S, false, d_log, &merged, rs)) return rc;
+                account(rs);
+            }
+            done = count;
+        }
+    }
+    if (done < count) {
+        AttractParams Q = P;
+        if (done) advance_first(Q.sp, first, done);
+        Q.count = count - done;
+        Q.per_problem = per_problem ? d_pp.p + done : nullptr;
+        AttractRun r;
+        if (int rc = launch_attract_pass(h, Q, false, d_log, &merged, r)) return rc;
+        account(r);
+    }
+
     if (merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
     uint32_t i = 0;
     for (auto& kv : merged) table[i++] = kv.second;
     *n_out = i;
-    if (n_no_attractor) *n_no_attractor = ctr.n_none;
+    if (n_no_attractor) *n_no_attractor = n_none;
 
     if (per_problem) {
+        const uint32_t nw = h->net.nw;
         std::vector<ProblemRec32> pp(count);
         HIPCHK(h, hipMemcpy(pp.data(), d_pp.p, count * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
         for (uint64_t p = 0; p < count; ++p) {
@@ -506,13 +619,13 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     }
     if (stats) {
         stats->problems = count;
-        stats->state_steps = ctr.steps_ref;
-        stats->executed_steps = ctr.steps_exec;
-        stats->kernel_ms = ms;
-        stats->kernel_launches = 1;
+        stats->state_steps = steps_ref;
+        stats->executed_steps = steps_exec;
+        stats->kernel_ms = kernel_ms;
+        stats->kernel_launches = launches;
         stats->total_ms = now_ms() - t_begin;
     }
-    if (ctr.step_limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit without closing its cycle");
+    if (limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit without closing its cycle");
     return BSX_OK;
 }
 

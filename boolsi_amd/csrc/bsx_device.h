@@ -75,6 +75,9 @@ struct Counters {               // zeroed before every launch
     unsigned long long log_cursor;      // records appended to the log / hits
     unsigned int log_overflow;
     unsigned int step_limit_hits;
+    unsigned long long n_stragglers;    // fast kernel: problems handed to the general kernel
+    unsigned int straggler_overflow;
+    unsigned int pad;
 };
 
 // Cache of known cycle states (DESIGN.md "cycle-state cache").  A trajectory enters its attractor at
@@ -115,8 +118,13 @@ struct AttractParams {
     Counters* ctr;
     LogRec* log;
     uint64_t log_cap;
-    ProblemRec32* per_problem;  // nullable
+    ProblemRec32* per_problem;  // nullable, indexed by problem offset
     CycleCache cc;
+    const uint32_t* offsets;    // nullable: work item i is problem offsets[i] (straggler pass)
+    uint32_t* stragglers;       // fast kernel: offsets of problems that hit no cached cycle state
+    uint64_t stragglers_cap;
+    uint32_t fast_steps;        // FAST phase length
+    uint32_t pad;
 };
 
 struct HitRec { uint64_t offset; uint64_t t; };

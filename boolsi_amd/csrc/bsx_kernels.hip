@@ -580,17 +580,26 @@ __device__ __forceinline__ void init_problem_simple(const DevSpace& sp, uint64_t
 // only (taken when cached attractors exist; ends at mu on the first cached cycle state) -> if nothing
 // is hit within kFastSteps the search restarts from s(T_p) in BRENT (detector + lookups) -> ADVANCE ->
 // MU -> DONE.  With a warm cache almost every lane ends in FAST, which carries no detector state.
-constexpr uint32_t kFastSteps = 48;
+//
+// FAST_ONLY = true builds the lean kernel used once attractors are cached: only IDLE / FAST / DONE
+// exist, the cache mirror is static for the whole launch, the probe of the current state is issued
+// together with the gather reads of the next step, and a lane that hits nothing within
+// P.fast_steps hands its problem to the general kernel through the straggler list.
+// Minimum waves per SIMD requested from the register allocator (a 512-thread workgroup is 2 per SIMD).
+constexpr int attract_min_waves(int nw, bool fast) {
+    return fast ? (nw == 1 ? 8 : nw == 2 ? 6 : nw == 4 ? 4 : 2) : (nw <= 2 ? 4 : 2);
+}
 
-template <int NW, int K, bool LDS_LUT>
-__global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
+template <int NW, int K, bool LDS_LUT, bool FAST_ONLY>
+__global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_attract(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
     const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
-    const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
-    const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
-    const bool use_cache = P.cc.enabled != 0;
+    const bool has_warmup = !FAST_ONLY && (P.sp.tp_origin | P.sp.n_pv) != 0;       // wave-uniform
+    const bool simple_space = FAST_ONLY || (P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv);
+    const bool use_cache = FAST_ONLY || P.cc.enabled != 0;
+    const uint32_t fast_steps = P.fast_steps;
     const uint32_t cmask = P.cc.lds_slots - 1;
 
     // LDS mirror of the cycle-state cache
@@ -641,9 +650,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
     uint32_t n_none = 0, limit_hits = 0;
 
     WaveQueue q{0, 0, true};
+    if constexpr (FAST_ONLY) vis = cache_visible(lc);      // static for the launch: nobody inserts
 
     // start of the search at s(T_p) = A: snapshot the cache, look s(T_p) itself up, pick the mode
     auto begin_search = [&]() {
+        if constexpr (FAST_ONLY) {          // s(T_p) itself is probed by the first iteration
+            t = 0; phase = PH_FAST;
+            return;
+        }
         copy_words<NW>(D, A);
         t = 0; pub = 0;
         vis = use_cache ? cache_visible(lc) : 0u;
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
 
             // ---- cycle-state cache upkeep (rare): pull what others published; one lane per newly
             //      detected attractor appends it to the journal
-            if (use_cache) {
+            if (!FAST_ONLY && use_cache) {
                 if (threadIdx.x == 0 && (++cc_rounds & 31u) == 0)
                     cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
                 uint64_t cand = __ballot(want_pub);
@@ -734,10 +748,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (phase == PH_IDLE && rank < avail) {
                         my_p = q.next + rank;
+                        if (!FAST_ONLY && P.offsets) my_p = P.offsets[my_p];
                         exec32 = 0;
                         if (simple_space) {
                             init_problem_simple<NW>(P.sp, my_p, A);
-                        } else {
+                        } else if constexpr (!FAST_ONLY) {
                             Problem<NW> pr;
                             init_problem<NW>(P.sp, my_p, pr);
                             copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
@@ -753,6 +768,34 @@ __global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
                 }
             }
             continue;       // re-evaluate the wave state (nothing to step if every lane is idle)
+        }
+
+        if constexpr (FAST_ONLY) {
+            // ---- lean iteration: probe the current state s(T_p + t) and compute s(T_p + t + 1) together
+            uint32_t nxt[NW], l2 = 0, k2[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) k2[w] = 0;
+            const bool hit = cache_lookup<NW>(lc, cmask, vis, A, l2, k2);
+            net_step<NW, K>(nv, A, fm0, fv0, nxt);
+            if (phase == PH_FAST) {
+                ++exec32;
+                const bool ok = hit && t <= cap_rel && l2 <= cap_rel - t;       // mu + lambda <= max_t - T_p
+                const bool lost = !hit && t >= fast_steps;
+                if (lost) {
+                    const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
+                    if (at < P.stragglers_cap) P.stragglers[at] = (uint32_t)my_p;
+                    else atomicOr(&P.ctr->straggler_overflow, 1u);
+                    steps_exec += exec32;
+                }
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { D[w] = hit ? k2[w] : D[w]; A[w] = nxt[w]; }
+                lam = l2;
+                cnt = ok ? t : 0u;
+                sub = ok ? 1u : 0u;
+                ++t;
+                phase = hit ? PH_DONE : (lost ? PH_IDLE : PH_FAST);
+            }
+            continue;
         }
 
         // ---- one network update per lane per iteration
@@ -773,7 +816,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_attract(const AttractParams P) {
         if (phase == PH_FAST) {
             const uint32_t t1 = t + 1;
             const bool ok = hit && t1 <= cap_rel && l2 <= cap_rel - t1;         // mu + lambda <= max_t - T_p
-            const bool restart = !hit && t1 >= kFastSteps;                      // not on a cached cycle yet
+            const bool restart = !hit && t1 >= fast_steps;                       // not on a cached cycle yet
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 A[w] = restart ? D[w] : nxt[w];
@@ -996,8 +1039,14 @@ __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
 // Launch dispatch over (NW, K, LDS_LUT).  NW in {1,2,4,8}; K in 1..6.
 template <int NW, int K>
 static hipError_t launch_attract_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_attract<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
+    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true, false>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_attract<NW, K, false, false>), grid, dim3(kBlock), shmem, st, P);
+    return hipGetLastError();
+}
+template <int NW, int K>
+static hipError_t launch_attract_fast_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_attract<NW, K, false, true>), grid, dim3(kBlock), shmem, st, P);
     return hipGetLastError();
 }
 template <int NW, int K>
@@ -1036,6 +1085,9 @@ static hipError_t launch_simulate_nk(bool lds, dim3 grid, size_t shmem, hipStrea
 hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
     BSX_DISPATCH(launch_attract_nk)
 }
+hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    BSX_DISPATCH(launch_attract_fast_nk)
+}
 hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
     BSX_DISPATCH(launch_target_nk)
 }
@@ -1048,11 +1100,13 @@ static hipError_t configure_nk(bool lds, dim3, size_t shmem, hipStream_t, const 
     const int bytes = (int)shmem;
     hipError_t e;
     if (lds) {
-        e = hipFuncSetAttribute((const void*)k_attract<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        e = hipFuncSetAttribute((const void*)k_attract<NW, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_attract<NW, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_target<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_simulate<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     } else {
-        e = hipFuncSetAttribute((const void*)k_attract<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        e = hipFuncSetAttribute((const void*)k_attract<NW, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_attract<NW, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_target<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_simulate<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
