@@ -602,8 +602,9 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     const uint32_t fast_steps = P.fast_steps;
     const uint32_t cmask = P.cc.lds_slots - 1;
 
-    // LDS mirror of the cycle-state cache
-    uint32_t* lc = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(smem_free) + 15) & ~uintptr_t(15));
+    // LDS mirror of the cycle-state cache (pointer arithmetic on `smem` keeps the LDS address space:
+    // a round trip through an integer would turn every probe into a flat load)
+    uint32_t* lc = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);
     uint32_t cc_seen = 0, cc_states = 0, cc_attr = 0, cc_rounds = 0;       // meaningful in thread 0 only
     uint32_t fm0[NW], fv0[NW];
 #pragma unroll
