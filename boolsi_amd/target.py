@@ -1,0 +1,73 @@
+"""
+Target mode: simulations that reach the target substate (after all perturbations), reference
+`boolsi/target.py` (target_master 13-88, simulate_until_target_substate_or_max_t 109-133).
+
+The search runs on the GPU (bsx_run_target: first t >= T_p with state & mask == code, none if the
+trajectory closes its cycle or max_t comes first); the states of the hits are then materialised
+with bsx_run_trajectories.  `-n` keeps the first n hits in enumeration (= index) order, exactly
+what the reference's single process finds before it stops (simulate.py:163-164, mpi.py:537-538):
+index tiles are processed in order and the search stops after the tile that completes n.
+"""
+import logging
+from math import inf
+
+from .batching import create_numeral_system_from_variations, problem_from_index
+from .compile import compile_network, compile_space, code_to_words
+from .simulate import Simulation, states_from_words
+
+TILE = 1 << 24
+
+
+def target_master(engine, origin_simulation_problem, simulation_problem_variations,
+                  target_substate_code, target_node_set, predecessor_node_lists, truth_tables,
+                  n_simulations_to_reach_target_substate, max_t, n_simulation_problems):
+    """-> list of Simulation (states s(0..t_hit)) in index order; log lines as target.py:45-86."""
+    log = logging.getLogger()
+    n_to_find = n_simulations_to_reach_target_substate
+    if n_to_find is not inf and n_to_find > n_simulation_problems:
+        log.warning('Requested {} simulations that reach target state, but only {} simulation '
+                    'problems provided. Will look for all simulations that reach target state.'.format(
+                        n_to_find, n_simulation_problems))
+        n_to_find = inf
+    log.info('Single process will be used to perform {} simulations and find {} that reach target states.'.format(
+        n_simulation_problems, 'all' if n_to_find is inf else n_to_find))
+
+    n_nodes = len(predecessor_node_lists)
+    net = compile_network(predecessor_node_lists, truth_tables)
+    space = compile_space(origin_simulation_problem, simulation_problem_variations)
+    engine.set_problem(net, space)
+    mask = code_to_words(sum(1 << n for n in target_node_set), net.n_words)
+    code = code_to_words(target_substate_code, net.n_words)
+    numeral_system = create_numeral_system_from_variations(simulation_problem_variations)
+
+    simulations = []
+    first = 0
+    while first < n_simulation_problems and len(simulations) < n_to_find:
+        count = min(TILE, n_simulation_problems - first)
+        hits, _ = engine.target(first, count, max_t, mask, code)
+        if n_to_find is not inf:
+            hits = hits[:int(n_to_find) - len(simulations)]
+        if len(hits):
+            trajs, _ = engine.trajectories(first, hits['offset'], hits['t'])
+            for h, traj in zip(hits, trajs):
+                _, fixed_nodes, perturbed_nodes_by_t = problem_from_index(
+                    first + int(h['offset']), origin_simulation_problem, simulation_problem_variations,
+                    numeral_system)
+                simulations.append(Simulation(states_from_words(traj, n_nodes), fixed_nodes, perturbed_nodes_by_t))
+        first += count
+
+    if n_to_find is not inf and len(simulations) >= n_to_find and first < n_simulation_problems:
+        log.info('Goal reached at {:.2%} of simulations to perform.'.format(first / n_simulation_problems))
+    wanted = n_simulation_problems if n_to_find is inf else n_to_find
+    if simulations:
+        if len(simulations) < wanted:
+            word = 'Only'
+        elif wanted < n_simulation_problems:
+            word = 'At least'
+        else:
+            word = 'All'
+        text = '{} {} simulations'.format(word, len(simulations))
+    else:
+        text = 'No simulations'
+    log.info('{} reach target state.'.format(text))
+    return simulations
