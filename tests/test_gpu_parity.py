@@ -250,3 +250,50 @@ def test_partition_invariance_and_conservation(eng):
             seen_min = min(seen_min, words_to_code(s))
         assert np.array_equal(s, s0)
         assert seen_min == words_to_code(s0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# paths of the attract orchestration that the synthetic sweeps do not reach
+
+def _chain_yaml(n=64):
+    """x0' = 0, x_i' = x_(i-1): the transient is the position of the highest set bit + 1, the only
+    attractor is the all-off fixed point.  Long transients = stragglers of the lean kernel."""
+    lines = ['nodes:'] + ['    - x{}'.format(i) for i in range(n)]
+    lines += ['update rules:', "    x0: '0'"] + ['    x{}: x{}'.format(i, i - 1) for i in range(1, n)]
+    lines += ['initial state:'] + ['    x{}: any'.format(i) for i in range(n)]
+    return '\n'.join(lines) + '\n'
+
+
+def test_lean_kernel_stragglers_and_fallback(eng):
+    cfg, net, space, orc = _setup(eng, _chain_yaml(), Mode.ATTRACT, math.inf)
+    _same_attract(eng, orc, 0, 1 << 16, None)                       # discovery + lean kernel, no stragglers
+    first = (1 << 48) - 58982
+    r = _same_attract(eng, orc, first, 1 << 16, None)               # ~10 % of the problems need > 48 steps
+    assert r.stats['kernel_launches'] in (1, 2, 3)
+    _same_attract(eng, orc, (1 << 48) - (1 << 15), 1 << 16, None)   # 50 % stragglers: list overflows, fallback
+    _same_attract(eng, orc, (1 << 60), 1 << 14, None)               # after the fallback the detector is used
+    _same_attract(eng, orc, (1 << 40), 1 << 14, 30)                 # time cap below the transient: none found
+    _same_attract(eng, orc, (1 << 20), 1 << 14, 30, 1)
+
+
+def test_attract_with_fixed_node_variations_uses_detector_only(eng):
+    # not reachable through the YAML front end (attract forbids variations) but allowed by the C-ABI:
+    # cycles differ per fixed-node variant, so the cycle cache must stay out of it
+    text = synth.network_yaml(40, 2, 77, initial={i: str(i & 1) for i in range(14, 40)},
+                              fixed={3: 'any?', 17: '0?', 21: 'any'},
+                              perturbations={5: {'1': '2, 6-7', 'any?': '9'}, 30: {'0?': '3'}})
+    cfg, net, space, orc = _setup(eng, text, Mode.SIMULATE, 4096)   # parsed in a mode that allows variations
+    assert space.n_problems == (1 << 14) * 3 * 2 * 2 * 3 * 2
+    _same_attract(eng, orc, 0, 1 << 15, 4096)
+    _same_attract(eng, orc, space.n_problems - 40000, 40000, 4096)
+    _same_attract(eng, orc, 123456, 5000, 12, 2)
+
+
+def test_largest_network_and_rule_width(eng):
+    # n = 256 (8 words, LUT read through L2), K = 6 mux tree, plus a 12-input rule on the wide path
+    text = synth.network_yaml(256, 6, 2566)
+    cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 64)
+    _same_attract(eng, orc, (1 << 255) + 12345, 3000, 64)
+    text = synth.network_yaml(20, 12, 2012)
+    cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 5000)
+    _same_attract(eng, orc, 0, 1 << 13, 5000)
