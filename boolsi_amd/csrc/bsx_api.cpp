@@ -21,6 +21,8 @@ hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipS
 hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
 hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
+hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
+                          HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
 hipError_t configure_kernels(int nw, int k, bool lds, size_t shmem);
 }  // namespace bsx
 
@@ -642,9 +644,10 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
 
+    if (count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call");
     const Launch L = plan_persistent(h, count, h->shmem);
-    DevBuf<HitRec> d_hits;
-    HIPCHK(h, d_hits.alloc(std::min<uint64_t>(cap, count)));
+    DevBuf<uint32_t> d_thit;
+    HIPCHK(h, d_thit.alloc(count));
     TargetParams P{};
     P.net = h->net;
     P.sp = h->sp;
@@ -658,8 +661,7 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
         if (2 * w + 1 < (uint32_t)kMaxW32) { P.tmask[2 * w + 1] = (uint32_t)(mask_words[w] >> 32); P.tcode[2 * w + 1] = (uint32_t)(code_words[w] >> 32); }
     }
     P.ctr = h->d_ctr.p;
-    P.hits = d_hits.p;
-    P.hits_cap = std::min<uint64_t>(cap, count);
+    P.t_hit = d_thit.p;
 
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -670,10 +672,32 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    if (ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "more hits than the caller's capacity");
-    static_assert(sizeof(HitRec) == sizeof(bsx_hit), "hit layout");
-    if (ctr.log_cursor) HIPCHK(h, hipMemcpy(hits, d_hits.p, ctr.log_cursor * sizeof(HitRec), hipMemcpyDeviceToHost));
-    *n_hits = ctr.log_cursor;
+    const uint64_t total_hits = ctr.log_cursor;
+    if (total_hits > cap) return fail(h, BSX_ERR_TABLE_FULL, "more hits than the caller's capacity");
+    if (total_hits) {
+        // ordered compaction of t_hit[] -> hit list (index order)
+        const uint32_t segs = (uint32_t)((count + 4095) / 4096);
+        DevBuf<uint32_t> d_cnt;
+        DevBuf<uint64_t> d_base;
+        DevBuf<HitRec> d_hits;
+        HIPCHK(h, d_cnt.alloc(segs));
+        HIPCHK(h, d_base.alloc(segs));
+        HIPCHK(h, d_hits.alloc(total_hits));
+        HIPCHK(h, launch_compact(d_thit.p, count, d_cnt.p, nullptr, nullptr, 0, false, h->stream));
+        std::vector<uint32_t> cnt(segs);
+        HIPCHK(h, hipMemcpyAsync(cnt.data(), d_cnt.p, segs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<uint64_t> base(segs);
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < segs; ++i) { base[i] = run; run += cnt[i]; }
+        if (run != total_hits) return fail(h, BSX_ERR_HIP, "hit compaction count mismatch");
+        HIPCHK(h, hipMemcpyAsync(d_base.p, base.data(), segs * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, launch_compact(d_thit.p, count, nullptr, d_base.p, d_hits.p, total_hits, true, h->stream));
+        static_assert(sizeof(HitRec) == sizeof(bsx_hit), "hit layout");
+        HIPCHK(h, hipMemcpyAsync(hits, d_hits.p, total_hits * sizeof(HitRec), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    *n_hits = total_hits;
     if (stats) {
         stats->problems = count;
         stats->state_steps = ctr.steps_ref;

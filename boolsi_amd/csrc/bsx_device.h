@@ -139,8 +139,7 @@ struct TargetParams {
     uint32_t tmask[kMaxW32];
     uint32_t tcode[kMaxW32];
     Counters* ctr;
-    HitRec* hits;
-    uint64_t hits_cap;
+    uint32_t* t_hit;            // [count] first hit time per problem, 0xFFFFFFFF = target not reached
 };
 
 struct SimParams {

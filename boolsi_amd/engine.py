@@ -162,8 +162,7 @@ class Engine:
         st = Stats()
         self._check(self._lib.bsx_run_target(self._h, C.byref(self.index(first)), count, _cap(max_t), ptr(m), ptr(c),
                                              ptr(hits), cap, C.byref(n_hits), C.byref(st)))
-        hits = hits[:n_hits.value]
-        return hits[np.argsort(hits['offset'], kind='stable')], st.as_dict()
+        return hits[:n_hits.value], st.as_dict()      # ascending offset order (ABI contract)
 
     def simulate(self, first, count, max_t, trajectories=True, final=True, digest=True):
         W = self.net.n_words

@@ -142,7 +142,7 @@ int  bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count,
                      bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
                      uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats);
 
-/* target (target.py:109-133): hits (unordered) into hits[0..*n_hits); mask/code are W words
+/* target (target.py:109-133): hits in ascending offset order into hits[0..*n_hits); mask/code are W words
  * (target node set / target substate code, input.py:580-661). */
 int  bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                     const uint64_t* mask_words, const uint64_t* code_words,
