@@ -519,6 +519,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     P.cc.enabled = (h->cache_enabled && h->sp.n_fv == 0) ? 1u : 0u;
     P.cc.lds_slots = h->cache_lds_slots;
     P.fast_steps = kFastSteps;
+    if (const char* sl = std::getenv("BSX_SERVICE_LANES")) P.pad = (uint32_t)std::atoi(sl);
 
     MergedTable merged;
     uint64_t n_none = 0, steps_ref = 0, steps_exec = 0;

@@ -447,43 +447,63 @@ __device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]) {
 // an entry's tag is the 1-based sequence number of its attractor and counts only when <= visible.
 constexpr int kCacheHeaderWords = 4;
 
+// One probe: loads the whole entry with no control flow in between (so the reads are issued together
+// with whatever else the caller has in flight) and classifies it.
+template <int NW>
+struct CacheProbe {
+    uint32_t tag, length;
+    uint32_t key[NW];
+    bool same;                  // entry holds exactly this state
+};
+
+template <int NW>
+__device__ __forceinline__ CacheProbe<NW> cache_probe(const uint32_t* base, uint32_t h, const uint32_t (&s)[NW]) {
+    constexpr int S = CacheLayout<NW>::kStride;
+    const uint32_t* e = base + h * S;
+    CacheProbe<NW> p;
+    if constexpr (NW == 1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+        p.tag = v.y; p.length = v.z; p.key[0] = v.w; p.same = v.x == s[0];
+    } else if constexpr (NW == 2) {
+        const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+        const uint2 k = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(e + 4, 8));
+        p.tag = v.z; p.length = v.w; p.key[0] = k.x; p.key[1] = k.y;
+        p.same = v.x == s[0] && v.y == s[1];
+    } else {
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { d |= e[w] ^ s[w]; p.key[w] = e[NW + 2 + w]; }
+        p.tag = e[NW]; p.length = e[NW + 1]; p.same = d == 0;
+    }
+    return p;
+}
+
+// Is `s` a state of an attractor with sequence number <= visible?  The first probe is branch-free;
+// only lanes that land on another attractor's (or a not yet visible) entry keep walking the chain
+// (the table is at most half full, so a walk ends at an empty tag).
 template <int NW>
 __device__ __forceinline__ bool cache_lookup(const uint32_t* lc, uint32_t mask, uint32_t visible,
-                                             const uint32_t (&s)[NW], uint32_t& length, uint32_t (&key)[NW]) {
-    constexpr int S = CacheLayout<NW>::kStride;
+                                             const uint32_t (&s)[NW], uint32_t& length, uint32_t (&key)[NW],
+                                             uint32_t* tag_out = nullptr) {
     const uint32_t* base = lc + kCacheHeaderWords;
     uint32_t h = hash_state<NW>(s) & mask;
-    for (;;) {      // the table is at most half full, so the walk ends at an empty tag
-        const uint32_t* e = base + h * S;
-        if constexpr (NW == 1) {
-            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-            if (v.y == 0) return false;
-            if (v.x == s[0] && v.y <= visible) { length = v.z; key[0] = v.w; return true; }
-        } else if constexpr (NW == 2) {
-            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-            if (v.z == 0) return false;
-            if (v.x == s[0] && v.y == s[1] && v.z <= visible) {
-                const uint2 k = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(e + 4, 8));
-                length = v.w; key[0] = k.x; key[1] = k.y;
-                return true;
-            }
-        } else {
-            uint32_t head[NW + 2];
-#pragma unroll
-            for (int i = 0; i < NW + 2; ++i) head[i] = e[i];
-            if (head[NW] == 0) return false;
-            bool same = head[NW] <= visible;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) same = same && head[w] == s[w];
-            if (same) {
-                length = head[NW + 1];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) key[w] = e[NW + 2 + w];
-                return true;
-            }
+    CacheProbe<NW> p = cache_probe<NW>(base, h, s);
+    bool hit = p.tag != 0 && p.tag <= visible && p.same;
+    bool walking = p.tag != 0 && !hit;
+    if (__builtin_expect(__ballot(walking) != 0, 0)) {
+        while (walking) {
+            h = (h + 1) & mask;
+            const CacheProbe<NW> q = cache_probe<NW>(base, h, s);
+            const bool here = q.tag != 0 && q.tag <= visible && q.same;
+            if (here) { p = q; hit = true; }
+            walking = q.tag != 0 && !here;
         }
-        h = (h + 1) & mask;
     }
+    length = p.length;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) key[w] = p.key[w];
+    if (tag_out) *tag_out = p.tag;
+    return hit;
 }
 
 __device__ __forceinline__ uint32_t cache_visible(const uint32_t* lc) {
@@ -600,6 +620,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     const bool simple_space = FAST_ONLY || (P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv);
     const bool use_cache = FAST_ONLY || P.cc.enabled != 0;
     const uint32_t fast_steps = P.fast_steps;
+    const uint32_t service_lanes = P.pad ? P.pad : kServiceLanes;
     const uint32_t cmask = P.cc.lds_slots - 1;
 
     // LDS mirror of the cycle-state cache (pointer arithmetic on `smem` keeps the LDS address space:
