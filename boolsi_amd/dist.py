@@ -97,6 +97,18 @@ class Comm:
             out.append(np.frombuffer(chunk.tobytes(), dtype=records.dtype))
         return out
 
+    def gather_concat(self, array):
+        """All-gather a numpy array along axis 0 (rank order = index order for range partitions)."""
+        if self.world == 1:
+            return array
+        flat = np.ascontiguousarray(array)
+        row = flat.dtype.itemsize * int(np.prod(flat.shape[1:], dtype=np.int64))
+        as_rows = flat.view(np.uint8).reshape(flat.shape[0], row) if flat.shape[0] else np.zeros((0, row), np.uint8)
+        rec = np.dtype([('b', 'u1', (row,))])
+        parts = self.allgather_records(as_rows.view(rec).reshape(-1))
+        joined = np.concatenate([p.view(np.uint8).reshape(-1, row) for p in parts])
+        return joined.view(flat.dtype).reshape((-1,) + flat.shape[1:])
+
     def shutdown(self):
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()

@@ -79,3 +79,15 @@ def simulate_digests(engine, origin_simulation_problem, simulation_problem_varia
         digests.append(dig)
         done += tile
     return np.concatenate(finals), np.concatenate(digests)
+
+
+def simulate_digests_partitioned(engine, origin_simulation_problem, simulation_problem_variations,
+                                 predecessor_node_lists, truth_tables, max_t, n_simulation_problems, comm=None):
+    """Whole problem space, range-partitioned over the ranks of `comm` (one GPU each); every rank gets
+    the final states and digests of all problems in index order (one all-gather each)."""
+    from .dist import Comm, partition
+    comm = comm or Comm()
+    first, count = partition(n_simulation_problems, comm.world, comm.rank)
+    finals, digests = simulate_digests(engine, origin_simulation_problem, simulation_problem_variations,
+                                       predecessor_node_lists, truth_tables, max_t, first, count)
+    return comm.gather_concat(finals), comm.gather_concat(digests)

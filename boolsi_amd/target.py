@@ -11,11 +11,43 @@ index tiles are processed in order and the search stops after the tile that comp
 import logging
 from math import inf
 
+import numpy as np
+
+from . import _lib
 from .batching import create_numeral_system_from_variations, problem_from_index
 from .compile import compile_network, compile_space, code_to_words
+from .dist import Comm, partition
 from .simulate import Simulation, states_from_words
 
 TILE = 1 << 24
+
+
+def find_hits(engine, first, count, max_t, mask, code, n_to_find=inf):
+    """(absolute problem index, t) of the hits in [first, first + count), index order, stopping after the
+    tile that completes n_to_find.  Returns (hits array of _lib.HIT with absolute offsets, problems scanned)."""
+    found, scanned, n = [], 0, 0
+    while scanned < count and n < n_to_find:
+        tile = min(TILE, count - scanned)
+        hits, _ = engine.target(first + scanned, tile, max_t, mask, code)
+        if len(hits):
+            hits = hits.copy()
+            hits['offset'] += np.uint64(scanned)
+            found.append(hits)
+            n += len(hits)
+        scanned += tile
+    out = np.concatenate(found) if found else np.zeros(0, _lib.HIT)
+    return out, scanned
+
+
+def target_hits_partitioned(engine, max_t, mask, code, n_simulation_problems, comm=None):
+    """Range-partitioned search over all problems (one rank per GPU); every rank gets all hits, in
+    index order (rank order = index order).  Problem indices here must fit 64 bits."""
+    comm = comm or Comm()
+    first, count = partition(n_simulation_problems, comm.world, comm.rank)
+    hits, _ = find_hits(engine, first, count, max_t, mask, code)
+    hits = hits.copy()
+    hits['offset'] += np.uint64(first)
+    return comm.gather_concat(hits)
 
 
 def target_master(engine, origin_simulation_problem, simulation_problem_variations,

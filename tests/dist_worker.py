@@ -33,11 +33,15 @@ def main():
     merged = merge_tables(gathered)
     none_all, steps_all = comm.allreduce_sum_int([none, steps])
     slowest = comm.allreduce_max(float(comm.rank))
+    # ragged 2-D gather in rank order (what target / simulate use to join per-rank outputs)
+    mine2d = np.arange(first, first + count, dtype=np.uint64).reshape(-1, 1).repeat(3, axis=1)[: (comm.rank + 1) * 5]
+    joined = comm.gather_concat(mine2d)
+    empty = comm.gather_concat(np.zeros((0, 2), np.uint32))
     comm.barrier()
     with open('{}.{}'.format(out_path, comm.rank), 'w') as f:
         json.dump({'rank': comm.rank, 'world': comm.world, 'first': first, 'count': count,
                    'merged': {str(k): v for k, v in merged.items()}, 'none': none_all, 'steps': steps_all,
-                   'slowest': slowest, 'per_rank_counts': [len(g) for g in gathered]}, f)
+                   'slowest': slowest, 'joined': joined.tolist(), 'empty_shape': list(empty.shape), 'per_rank_counts': [len(g) for g in gathered]}, f)
     comm.shutdown()
 
 

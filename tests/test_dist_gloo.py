@@ -67,4 +67,9 @@ def test_gloo_allgather_merge_equals_single_process(tmp_path, world):
         assert r['merged'] == expect            # identical on every rank
         assert r['none'] == none and r['steps'] == steps
         assert r['slowest'] == world - 1
+        expect_joined = []
+        for q in range(world):
+            lo, cnt = partition(20013, world, q)
+            expect_joined += [[v, v, v] for v in range(lo, lo + cnt)][: (q + 1) * 5]
+        assert r['joined'] == expect_joined and r['empty_shape'] == [0, 2]
     assert sum(r['count'] for r in results) == 20013
