@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,7 @@ hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipS
 hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
 hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
+hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P);
 hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
 hipError_t configure_kernels(int nw, int k, bool lds, size_t shmem);
@@ -77,6 +79,11 @@ struct bsx_engine {
     DevBuf<unsigned int> d_cc_claims;
     DevBuf<unsigned int> d_cc_count;
     DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
+
+    // host copies for the bit-sliced simulate kernel's node descriptors
+    std::vector<uint32_t> h_pred_offsets, h_pred_idx;
+    std::vector<uint64_t> h_tt0;        // first table word of every node (all of it when k <= 6)
+    std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
 
     // problem space
     bool have_space = false;
@@ -256,6 +263,10 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     HIPCHK(h, h->d_wide_preds.upload(wpreds));
     HIPCHK(h, h->d_wide_tt.upload(wtt));
 
+    h->h_pred_offsets.assign(pred_offsets, pred_offsets + n_nodes + 1);
+    h->h_pred_idx.assign(pred_idx, pred_idx + pred_offsets[n_nodes]);
+    h->h_tt0.resize(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; ++i) h->h_tt0[i] = tt_words[tt_word_offsets[i]];
     h->n_nodes = n_nodes;
     h->w64 = (n_nodes + 63) / 64;
     h->net.n_nodes = n_nodes;
@@ -343,6 +354,13 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
         const size_t at = (size_t)sched[j].t * nw + (sched[j].node >> 5);
         const uint32_t m = 1u << (sched[j].node & 31);
         if (sched[j].value) { set[at] |= m; clr[at] &= ~m; } else { clr[at] |= m; set[at] &= ~m; }
+    }
+    {
+        std::vector<std::array<uint32_t, 3>> ordered;
+        for (uint32_t j = 0; j < n_sched; ++j) ordered.push_back({sched[j].t, sched[j].node, sched[j].value});
+        std::stable_sort(ordered.begin(), ordered.end(), [](const auto& a, const auto& b) { return a[0] < b[0]; });
+        h->h_sched.clear();
+        for (const auto& e : ordered) { h->h_sched.push_back(e[0]); h->h_sched.push_back(e[1]); h->h_sched.push_back(e[2]); }
     }
     HIPCHK(h, h->d_any.upload(any));
     HIPCHK(h, h->d_fv.upload(fv));
@@ -769,6 +787,72 @@ static int run_sim_common(bsx_handle h, const bsx_index* first, uint64_t count, 
     return BSX_OK;
 }
 
+// Final states of a fixed-length run through the bit-sliced kernel (no variations, no wide rules).
+static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                          uint64_t* final_states, bsx_stats* stats) {
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    const uint32_t n = h->n_nodes, K = h->net.k_mux, W = h->w64;
+    const uint32_t rows = (n + 3) & ~3u;
+    std::vector<uint32_t> desc((size_t)rows * 8, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
+        for (uint32_t j = 0; j < k; ++j) desc[(size_t)i * 8 + j] = h->h_pred_idx[h->h_pred_offsets[i] + j];
+        uint64_t tt = 0;
+        const bool fixed = (h->sp.fixmask[i >> 5] >> (i & 31)) & 1u;
+        if (fixed) tt = ((h->sp.fixval[i >> 5] >> (i & 31)) & 1u) ? ~0ull : 0ull;     // model.py:45-47
+        else
+            for (uint32_t idx = 0; idx < (1u << K); ++idx)
+                if ((h->h_tt0[i] >> (idx & ((1u << k) - 1))) & 1ull) tt |= 1ull << idx;
+        desc[(size_t)i * 8 + 6] = (uint32_t)tt;
+        desc[(size_t)i * 8 + 7] = (uint32_t)(tt >> 32);
+    }
+    DevBuf<uint32_t> d_desc, d_sched;
+    DevBuf<uint64_t> d_final;
+    HIPCHK(h, d_desc.upload(desc));
+    HIPCHK(h, d_sched.upload(h->h_sched));
+    HIPCHK(h, d_final.alloc(count * W));
+
+    SlicedParams P{};
+    P.sp = h->sp;
+    set_first(P.sp, first);
+    P.n_nodes = n;
+    P.n_rows = rows;
+    P.n_sched = (uint32_t)(h->h_sched.size() / 3);
+    P.w64 = W;
+    P.desc = d_desc.p;
+    P.sched = d_sched.p;
+    P.count = count;
+    P.max_t = max_t;
+    P.final_states = d_final.p;
+    P.ctr = h->d_ctr.p;
+
+    const size_t shmem = (size_t)rows * (8 + 128) * 4;
+    const uint64_t groups = (count + 2047) / 2048;
+    const uint64_t per_cu = std::max<size_t>(1, (160 * 1024) / shmem);
+    const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)h->prop.multiProcessorCount * per_cu));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_simulate_sliced((int)h->net.nw, (int)K, dim3((uint32_t)blocks), shmem, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    Counters ctr{};
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    HIPCHK(h, hipMemcpy(final_states, d_final.p, count * W * 8, hipMemcpyDeviceToHost));
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = ctr.steps_ref;
+        stats->executed_steps = ctr.steps_exec;
+        stats->kernel_ms = ms;
+        stats->kernel_launches = 1;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    return BSX_OK;
+}
+
 extern "C" int bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                                 uint64_t* trajectories, uint64_t* final_states, uint64_t* digests,
                                 bsx_stats* stats) {
@@ -776,6 +860,13 @@ extern "C" int bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t c
     if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
     if (int rc = check_index(h, first)) return rc;
     if (max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
+    // Long fixed-length runs that only want final states go through the bit-sliced kernel
+    // (BSX_SLICED=0 forces the per-lane kernel, for A/B runs and tests).
+    const char* sl_env = std::getenv("BSX_SLICED");
+    const bool sliced_ok = !(sl_env && sl_env[0] == '0') && final_states && !trajectories && !digests &&
+                           !h->sp.n_fv && !h->sp.n_pv && !h->net.n_wide && max_t >= 64 && max_t < kStepLimit &&
+                           count >= 2048 && (size_t)((h->n_nodes + 3) & ~3u) * 136 * 4 <= 160 * 1024;
+    if (sliced_ok && count) return run_sim_sliced(h, first, count, max_t, final_states, stats);
     const uint64_t words = trajectories ? count * (max_t + 1) * h->w64 : 0;
     return run_sim_common(h, first, count, max_t, nullptr, nullptr, nullptr, words, trajectories, final_states,
                           digests, stats);

@@ -158,4 +158,20 @@ struct SimParams {
     Counters* ctr;
 };
 
+// Bit-sliced simulate kernel (fixed-length runs, no per-problem variations): one lane owns 32
+// trajectories, the state is an n x 64-lane matrix of 32-bit words in LDS, double buffered.
+struct SlicedParams {
+    DevSpace sp;
+    uint32_t n_nodes;
+    uint32_t n_rows;            // n_nodes rounded up to the node batch
+    uint32_t n_sched;
+    uint32_t w64;
+    const uint32_t* desc;       // [n_rows][8]: 6 predecessor rows, truth table (64 bits, replicated to 2^K)
+    const uint32_t* sched;      // [n_sched][3] (t, node, value) sorted by t
+    uint64_t count;
+    uint64_t max_t;
+    uint64_t* final_states;     // [count][w64]
+    Counters* ctr;
+};
+
 }  // namespace bsx

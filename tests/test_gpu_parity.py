@@ -297,3 +297,29 @@ def test_largest_network_and_rule_width(eng):
     text = synth.network_yaml(20, 12, 2012)
     cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 5000)
     _same_attract(eng, orc, 0, 1 << 13, 5000)
+
+
+# ---------------------------------------------------------------------------------------------------
+# bit-sliced simulate kernel (final states of long fixed-length runs)
+
+@pytest.mark.parametrize('name,text,max_t,first,count', [
+    ('config5_like', synth.config5_yaml(max_t=700, n_any=14), 700, 100, 5000),          # ragged last group
+    ('n200_k2', synth.network_yaml(200, 2, 2002), 100, (1 << 150) + 7, 4096),
+    ('n40_k5_fixed_pert', synth.network_yaml(40, 5, 40, initial={i: ('any' if i % 3 else str(i & 1)) for i in range(40)},
+                                             fixed={3: '1', 17: '0'},
+                                             perturbations={5: {'1': '2, 6-7, 90'}, 30: {'0': '3, 64'}}), 128, 12345, 6000),
+    ('n64_k1', synth.network_yaml(64, 1, 641), 64, 0, 2048),
+    ('n250_k4', synth.network_yaml(250, 4, 2504), 70, (1 << 249) - 5000, 3000),
+], ids=lambda v: v if isinstance(v, str) and len(v) < 30 else None)
+def test_sliced_simulate_matches_oracle_and_per_lane_kernel(eng, name, text, max_t, first, count):
+    cfg, net, space, orc = _setup(eng, text, Mode.SIMULATE, max_t)
+    _, final, _, st = eng.simulate(first, count, max_t, trajectories=False, digest=False)     # sliced kernel
+    _, ofinal, _, _ = orc.simulate(first, count, max_t, want_traj=False, n_threads=8)
+    assert np.array_equal(final, ofinal)
+    assert st['state_steps'] == count * max_t
+    os.environ['BSX_SLICED'] = '0'
+    try:
+        _, final2, _, _ = eng.simulate(first, count, max_t, trajectories=False, digest=False)  # per-lane kernel
+    finally:
+        os.environ.pop('BSX_SLICED')
+    assert np.array_equal(final, final2)
