@@ -794,7 +794,7 @@ static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, 
     HIPCHK(h, hipSetDevice(h->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
     const uint32_t n = h->n_nodes, K = h->net.k_mux, W = h->w64;
-    const uint32_t rows = (n + 3) & ~3u;
+    const uint32_t rows = (n + 15) & ~15u;     // node batch (4) x waves per workgroup (4)
     std::vector<uint32_t> desc((size_t)rows * 8, 0);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
@@ -865,7 +865,7 @@ extern "C" int bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t c
     const char* sl_env = std::getenv("BSX_SLICED");
     const bool sliced_ok = !(sl_env && sl_env[0] == '0') && final_states && !trajectories && !digests &&
                            !h->sp.n_fv && !h->sp.n_pv && !h->net.n_wide && max_t >= 64 && max_t < kStepLimit &&
-                           count >= 2048 && (size_t)((h->n_nodes + 3) & ~3u) * 136 * 4 <= 160 * 1024;
+                           count >= 2048 && (size_t)((h->n_nodes + 15) & ~15u) * 136 * 4 <= 160 * 1024;
     if (sliced_ok && count) return run_sim_sliced(h, first, count, max_t, final_states, stats);
     const uint64_t words = trajectories ? count * (max_t + 1) * h->w64 : 0;
     return run_sim_common(h, first, count, max_t, nullptr, nullptr, nullptr, words, trajectories, final_states,

@@ -1118,31 +1118,36 @@ __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
 // instructions per node update of one trajectory, against ~2 + 0.4 for the one-trajectory-per-lane
 // kernel at n = 128, K = 3.
 constexpr int kSlicedBatch = 4;      // nodes evaluated between LDS write-backs (independent reads overlap)
+constexpr int kSlicedWaves = 4;      // waves of a workgroup share the 2048 trajectories and split the nodes
 
 template <int NW, int K>
-__global__ __launch_bounds__(64) void k_simulate_sliced(const SlicedParams P) {
+__global__ __launch_bounds__(64 * kSlicedWaves) void k_simulate_sliced(const SlicedParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int lane = threadIdx.x;
-    const uint32_t n = P.n_nodes, rows = P.n_rows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = P.n_nodes, rows = P.n_rows;      // rows is a multiple of kSlicedBatch * kSlicedWaves
+    const uint32_t rows_per_wave = rows / kSlicedWaves;
     uint32_t* desc = smem;                      // [rows][8]
     uint32_t* buf0 = desc + rows * 8;           // [rows][64]
     uint32_t* buf1 = buf0 + rows * 64;
-    for (uint32_t i = lane; i < rows * 8; i += 64) desc[i] = P.desc[i];
+    for (uint32_t i = threadIdx.x; i < rows * 8; i += blockDim.x) desc[i] = P.desc[i];
 
     const uint64_t n_groups = (P.count + 2047) / 2048;
     for (uint64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
         const uint64_t base = group * 2048 + (uint64_t)lane * 32;
         // ---- initial states: one 32-node word at a time, packed words of the lane's 32 trajectories
-        //      into buf1 as scratch (32 x 64 words), then transposed into 32 rows of buf0
+        //      into buf1 as scratch (32 x 64 words), then transposed into 32 rows of buf0; the waves
+        //      split the trajectories (k) and then the rows (b)
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            for (uint32_t k = 0; k < 32; ++k) {
+            __syncthreads();
+            for (uint32_t k = wave * 8; k < wave * 8 + 8; ++k) {
                 Problem<NW> pr;
                 if (base + k < P.count) init_problem<NW>(P.sp, base + k, pr);
                 else pr.s[w] = 0;
                 buf1[k * 64 + lane] = pr.s[w];
             }
-            for (uint32_t b = 0; b < 32; ++b) {
+            __syncthreads();
+            for (uint32_t b = wave * 8; b < wave * 8 + 8; ++b) {
                 const uint32_t node = w * 32 + b;
                 if (node >= rows) break;
                 uint32_t row = 0;
@@ -1152,13 +1157,14 @@ __global__ __launch_bounds__(64) void k_simulate_sliced(const SlicedParams P) {
                 buf0[node * 64 + lane] = row;
             }
         }
+        __syncthreads();
 
-        // ---- T synchronous updates
+        // ---- T synchronous updates; wave v evaluates rows [v * rows / 4, (v + 1) * rows / 4)
         uint32_t* cur = buf0;
         uint32_t* nxt = buf1;
         uint32_t sched_at = 0;
         for (uint64_t t = 1; t <= P.max_t; ++t) {
-            for (uint32_t i0 = 0; i0 < rows; i0 += kSlicedBatch) {
+            for (uint32_t i0 = wave * rows_per_wave; i0 < (wave + 1) * rows_per_wave; i0 += kSlicedBatch) {
                 uint32_t out[kSlicedBatch];
 #pragma unroll
                 for (int u = 0; u < kSlicedBatch; ++u) {
@@ -1188,18 +1194,21 @@ __global__ __launch_bounds__(64) void k_simulate_sliced(const SlicedParams P) {
 #pragma unroll
                 for (int u = 0; u < kSlicedBatch; ++u) nxt[(i0 + u) * 64 + lane] = out[u];
             }
+            __syncthreads();
             // perturbation override at time t (model.py:68-71): whole rows, the schedule is the same
             // for every trajectory (spaces with variations use the per-lane kernel)
             while (sched_at < P.n_sched && P.sched[3 * sched_at] < t) ++sched_at;
+            const uint32_t sched_first = sched_at;
             while (sched_at < P.n_sched && P.sched[3 * sched_at] == t) {
-                nxt[P.sched[3 * sched_at + 1] * 64 + lane] = P.sched[3 * sched_at + 2] ? 0xFFFFFFFFu : 0u;
+                if (wave == 0) nxt[P.sched[3 * sched_at + 1] * 64 + lane] = P.sched[3 * sched_at + 2] ? 0xFFFFFFFFu : 0u;
                 ++sched_at;
             }
+            if (sched_at != sched_first) __syncthreads();      // uniform: every wave walks the same schedule
             uint32_t* swap = cur; cur = nxt; nxt = swap;
         }
 
-        // ---- final states back to one word sequence per trajectory
-        for (uint32_t k = 0; k < 32; ++k) {
+        // ---- final states back to one word sequence per trajectory (waves split the trajectories)
+        for (uint32_t k = wave * 8; k < wave * 8 + 8; ++k) {
             if (base + k >= P.count) break;
             uint32_t s[NW];
 #pragma unroll
@@ -1218,8 +1227,9 @@ __global__ __launch_bounds__(64) void k_simulate_sliced(const SlicedParams P) {
                 if ((uint32_t)w < P.w64) P.final_states[(base + k) * P.w64 + w] = word;
             }
         }
+        __syncthreads();
     }
-    if (lane == 0 && blockIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         atomicAdd(&P.ctr->steps_ref, (unsigned long long)(P.count * P.max_t));
         atomicAdd(&P.ctr->steps_exec, (unsigned long long)(P.count * P.max_t));
     }
@@ -1229,7 +1239,7 @@ template <int NW, int K>
 static hipError_t launch_sliced_nk(bool, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
     hipError_t e = hipFuncSetAttribute((const void*)k_simulate_sliced<NW, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_simulate_sliced<NW, K>), grid, dim3(64), shmem, st, P);
+    hipLaunchKernelGGL((k_simulate_sliced<NW, K>), grid, dim3(64 * kSlicedWaves), shmem, st, P);
     return hipGetLastError();
 }
 
