@@ -1,7 +1,7 @@
 // Host side of the C-ABI (include/bsx.h): handle management, lowering of the network / problem-space
 // tables into the device layout (gather LUT, bit-packed truth-table masks, dense perturbation
 // schedule), launches, and the merge of the device attractor log.  No CPU compute path exists here:
-// every bsx_run_* ends in a gfx950 kernel launch (bsx_kernels.hip).
+// every bsx_run_* ends in gfx950 kernel launches (bsx_attract.hip, bsx_target.hip, bsx_simulate.hip, bsx_sliced.hip).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -25,7 +25,9 @@ hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hip
 hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P);
 hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
-hipError_t configure_kernels(int nw, int k, bool lds, size_t shmem);
+hipError_t configure_attract(int nw, int k, bool lds, size_t shmem);
+hipError_t configure_target(int nw, int k, bool lds, size_t shmem);
+hipError_t configure_simulate(int nw, int k, bool lds, size_t shmem);
 }  // namespace bsx
 
 using namespace bsx;
@@ -293,7 +295,9 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     h->lut_in_lds = mask_bytes + lut_bytes + cache_bytes + 64 <= 144 * 1024;
     h->shmem = mask_bytes + (h->lut_in_lds ? lut_bytes : 0) + 64;
     h->shmem_attract = h->shmem + cache_bytes;
-    HIPCHK(h, configure_kernels((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract));
+    HIPCHK(h, configure_attract((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract));
+    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
+    HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
     h->have_net = true;
     return BSX_OK;
 }

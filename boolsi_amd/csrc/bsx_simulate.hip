@@ -1,0 +1,78 @@
+// per-lane simulate kernel (trajectory / final state / digest sinks)
+#include "bsx_kernels_common.h"
+
+namespace bsx {
+
+// ------------------------------------------------------------------------------------------------
+// simulate: s(0..T) by plain stepping (simulate.py:97-131 == S11); sinks: trajectory, final state, digest.
+template <int NW, int K, bool LDS_LUT>
+__global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t steps = 0;
+    for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < P.count; qi += stride) {
+        const uint64_t p = P.offsets ? P.offsets[qi] : qi;
+        const uint64_t T = P.t_len ? P.t_len[qi] : P.max_t;
+        Problem<NW> pr;
+        init_problem<NW>(P.sp, p, pr);
+        uint32_t s[NW];
+        copy_words<NW>(s, pr.s);
+        uint64_t* out = P.traj ? P.traj + (P.out_offsets ? P.out_offsets[qi] : qi * (P.max_t + 1) * P.w64) : nullptr;
+        uint64_t dg = kDigestSeed;
+        for (uint64_t t = 0;; ++t) {
+#pragma unroll
+            for (int w = 0; w < (NW + 1) / 2; ++w) {
+                uint64_t word = s[2 * w];
+                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                if ((uint32_t)w < P.w64) {
+                    if (out) out[t * P.w64 + w] = word;
+                    dg = (dg ^ word) * kDigestPrime;
+                }
+            }
+            if (t == T) break;
+            uint32_t nxt[NW];
+            net_step<NW, K>(nv, s, pr.fm, pr.fv, nxt);
+            if (t + 1 <= pr.tp) apply_perturbations<NW>(P.sp, (uint32_t)(t + 1), pr.pv_digits, nxt);
+            copy_words<NW>(s, nxt);
+            ++steps;
+        }
+        if (P.final_states) {
+#pragma unroll
+            for (int w = 0; w < (NW + 1) / 2; ++w) {
+                uint64_t word = s[2 * w];
+                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                if ((uint32_t)w < P.w64) P.final_states[qi * P.w64 + w] = word;
+            }
+        }
+        if (P.digests) P.digests[qi] = dg;
+    }
+    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps);
+    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps);
+}
+
+
+template <int NW, int K>
+static hipError_t launch_simulate_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
+    if (lds) hipLaunchKernelGGL((k_simulate<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_simulate<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
+    return hipGetLastError();
+}
+template <int NW, int K>
+static hipError_t configure_simulate_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
+    return lds ? hipFuncSetAttribute((const void*)k_simulate<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
+               : hipFuncSetAttribute((const void*)k_simulate<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+}
+
+hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
+    BSX_DISPATCH(launch_simulate_nk)
+}
+hipError_t configure_simulate(int nw, int k, bool lds, size_t shmem) {
+    const dim3 grid(1);
+    const hipStream_t st = nullptr;
+    const int P = 0;
+    BSX_DISPATCH(configure_simulate_nk)
+}
+
+}  // namespace bsx

@@ -1,0 +1,178 @@
+// target kernel, hit compaction, launchers
+#include "bsx_kernels_common.h"
+
+namespace bsx {
+
+template <int NW>
+__device__ __forceinline__ bool target_hit(const uint32_t (&s)[NW], const uint32_t (&tm)[NW], const uint32_t (&tc)[NW]) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) d |= (s[w] & tm[w]) ^ tc[w];
+    return d == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// target: stop at the first t >= T_p with (state & mask) == code; a trajectory that closes its cycle
+// (or hits max_t) first reaches nothing (target.py:109-133 over model.py:152-236, S12).
+// Output: t_hit[p] for every problem (kNotReached if none); k_compact_* turn it into the hit list.
+constexpr uint32_t kNotReached = 0xFFFFFFFFu;
+
+template <int NW, int K, bool LDS_LUT>
+__global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const TargetParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const int lane = threadIdx.x & 63;
+    const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
+
+    uint32_t A[NW], B[NW], fm[NW], fv[NW], tm[NW], tc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { A[w] = B[w] = 0; fm[w] = P.sp.fixmask[w]; fv[w] = P.sp.fixval[w]; tm[w] = P.tmask[w]; tc[w] = P.tcode[w]; }
+    // t: absolute time; lam/power: Brent's counters (only to notice that the cycle closed)
+    uint32_t phase = PH_IDLE, t = 0, tp = P.sp.tp_origin, lam = 0, power = 1;
+    const uint32_t t_cap = (P.cap_rel_inf || P.max_t >= kStepLimit) ? kStepLimit : (uint32_t)P.max_t;
+    uint64_t pv_digits = 0, my_p = 0;
+    uint64_t steps_exec = 0;
+    uint32_t limit_hits = 0, n_hits = 0;
+    WaveQueue q{0, 0, true};
+
+    for (;;) {
+        const uint32_t n_run = __popcll(__ballot(phase >= PH_WARM));
+        const bool work_left = q.more || q.next < q.end;
+        if (n_run == 0 && !work_left) break;
+        if (work_left && (64u - n_run >= kServiceLanes || n_run == 0)) {
+            // ---- refill idle lanes with the next problems of the wave's chunk
+            if (q.next == q.end) {
+                const uint64_t base = grab_chunk(&P.ctr->cursor, P.chunk, lane);
+                if (base >= P.count) q.more = false;
+                else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
+            }
+            const uint64_t avail = q.end - q.next;
+            const uint64_t idle = __ballot(phase == PH_IDLE);
+            if (avail && idle) {
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                if (phase == PH_IDLE && rank < avail) {
+                    my_p = q.next + rank;
+                    if (simple_space) {
+                        init_problem_simple<NW>(P.sp, my_p, A);
+                    } else {
+                        Problem<NW> pr;
+                        init_problem<NW>(P.sp, my_p, pr);
+                        copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
+                        pv_digits = pr.pv_digits; tp = pr.tp;
+                    }
+                    t = 0; lam = 0; power = 1;
+                    copy_words<NW>(B, A);
+                    phase = tp > 0 ? PH_WARM : PH_BRENT;
+                }
+                const uint64_t n_idle = (uint64_t)__popcll(idle);
+                q.next += n_idle < avail ? n_idle : avail;
+            }
+            continue;
+        }
+
+        // ---- check the current state (covers s(T_p), model.py:200), then one network update
+        uint32_t nxt[NW];
+        net_step<NW, K>(nv, A, fm, fv, nxt);
+        if (phase == PH_BRENT) {
+            const bool reached = target_hit<NW>(A, tm, tc);
+            const bool capped = !reached && t >= t_cap;
+            const uint32_t lam1 = lam + 1;
+            const bool closed = !reached && !capped && eq_words<NW>(nxt, B);     // every state has been checked
+            const bool tele = !closed && lam1 == power;
+            if (reached | capped | closed) {
+                P.t_hit[my_p] = reached ? t : kNotReached;
+                n_hits += reached ? 1u : 0u;
+                limit_hits += (capped && t_cap == kStepLimit) ? 1u : 0u;
+                steps_exec += t;
+                phase = PH_IDLE;
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { A[w] = nxt[w]; B[w] = tele ? nxt[w] : B[w]; }
+                power = tele ? power << 1 : power;
+                lam = tele ? 0u : lam1;
+                ++t;
+            }
+        } else if (phase == PH_WARM) {
+            ++t;
+            apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
+            copy_words<NW>(A, nxt);
+            if (t == tp) { phase = PH_BRENT; lam = 0; power = 1; copy_words<NW>(B, A); }
+        }
+    }
+    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_exec);
+    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps_exec);
+    if (n_hits) atomicAdd(&P.ctr->log_cursor, (unsigned long long)n_hits);
+    if (limit_hits) atomicAdd(&P.ctr->step_limit_hits, limit_hits);
+}
+
+// Ordered stream compaction of t_hit[] into the hit list: pass 1 counts hits per segment, the host
+// scans the (small) count array, pass 2 writes each segment's hits at its base in index order.
+constexpr uint32_t kCompactSegment = 4096;
+
+__global__ __launch_bounds__(256) void k_compact_count(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts) {
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kCompactSegment;
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < kCompactSegment; i += 256)
+        if (base + i < count && t_hit[base + i] != kNotReached) ++mine;
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) seg_counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_compact_write(const uint32_t* t_hit, uint64_t count, const uint64_t* seg_base,
+                                                       HitRec* hits, uint64_t hits_cap) {
+    __shared__ uint32_t wave_tot[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kCompactSegment;
+    uint64_t out = seg_base[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t c0 = 0; c0 < kCompactSegment; c0 += 256) {
+        const uint64_t p = base + c0 + threadIdx.x;
+        const uint32_t t = p < count ? t_hit[p] : kNotReached;
+        const bool hit = t != kNotReached;
+        const uint64_t m = __ballot(hit);
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        const uint32_t all = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        if (hit && out + before < hits_cap) { hits[out + before].offset = p; hits[out + before].t = t; }
+        out += all;
+        __syncthreads();
+    }
+}
+
+
+template <int NW, int K>
+static hipError_t launch_target_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
+    if (lds) hipLaunchKernelGGL((k_target<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_target<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
+    return hipGetLastError();
+}
+template <int NW, int K>
+static hipError_t configure_target_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
+    return lds ? hipFuncSetAttribute((const void*)k_target<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
+               : hipFuncSetAttribute((const void*)k_target<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+}
+
+hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
+    BSX_DISPATCH(launch_target_nk)
+}
+hipError_t configure_target(int nw, int k, bool lds, size_t shmem) {
+    const dim3 grid(1);
+    const hipStream_t st = nullptr;
+    const int P = 0;
+    BSX_DISPATCH(configure_target_nk)
+}
+hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
+                          HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st) {
+    const uint32_t blocks = (uint32_t)((count + kCompactSegment - 1) / kCompactSegment);
+    if (!write_pass) hipLaunchKernelGGL(k_compact_count, dim3(blocks), dim3(256), 0, st, t_hit, count, seg_counts);
+    else hipLaunchKernelGGL(k_compact_write, dim3(blocks), dim3(256), 0, st, t_hit, count, seg_base, hits, hits_cap);
+    return hipGetLastError();
+}
+
+}  // namespace bsx
