@@ -9,7 +9,7 @@ constexpr int kBlock = 512;                 // 8 waves per workgroup share one L
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxW32 = 8;                  // 32-bit words per state (n <= 256)
 constexpr int kMaxMuxK = 6;                 // nodes with more predecessors take the "wide" path
-constexpr int kTableSlots = 64;             // per-wave LDS attractor table: one slot per lane
+constexpr int kTableSlots = 64;             // per-wave attractor table: one slot per lane (registers)
 constexpr uint32_t kStepLimit = 1u << 30;   // internal per-trajectory step limit (u32 counters)
 constexpr uint64_t kDigestSeed = 0xCBF29CE484222325ull;
 constexpr uint64_t kDigestPrime = 0x100000001B3ull;
