@@ -80,6 +80,10 @@ struct bsx_engine {
     DevBuf<CycleRecord> d_cc_journal;
     DevBuf<unsigned int> d_cc_claims;
     DevBuf<unsigned int> d_cc_count;
+
+    // scratch kept across calls (grow-only): hipMalloc / hipFree per call cost ~1 ms of a 16 ms step
+    DevBuf<LogRec> d_log;
+    DevBuf<uint32_t> d_strag;
     DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
 
     // host copies for the bit-sliced simulate kernel's node descriptors
@@ -520,7 +524,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     if (max_t != BSX_T_INF && max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
     if (count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call");
 
-    DevBuf<LogRec> d_log;
+    DevBuf<LogRec>& d_log = h->d_log;
     DevBuf<ProblemRec32> d_pp;
     if (per_problem) HIPCHK(h, d_pp.alloc(count));
 
@@ -573,9 +577,9 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     }
     if (use_fast && done < count) {
         const uint64_t rest = count - done;
-        DevBuf<uint32_t> d_strag;
+        DevBuf<uint32_t>& d_strag = h->d_strag;
         const uint64_t strag_cap = rest / 4 + 4096;
-        HIPCHK(h, d_strag.alloc(strag_cap));
+        if (d_strag.n < strag_cap) HIPCHK(h, d_strag.alloc(strag_cap));
         AttractParams Q = P;
         advance_first(Q.sp, first, done);
         Q.count = rest;
