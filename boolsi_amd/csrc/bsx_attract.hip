@@ -86,8 +86,15 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
 
     // start of the search at s(T_p) = A: snapshot the cache, look s(T_p) itself up, pick the mode
     auto begin_search = [&]() {
-        if constexpr (FAST_ONLY) {          // s(T_p) itself is probed by the first iteration
-            t = 0; phase = PH_FAST;
+        if constexpr (FAST_ONLY) {          // probe s(T_p) itself, then step + probe per iteration
+            uint32_t l0 = 0, k0[NW], tag0 = 0;
+            t = 0;
+            if (cache_lookup<NW>(lc, cmask, vis, A, l0, k0, &tag0)) {
+                phase = PH_DONE; lam = l0; pub = tag0; cnt = 0; sub = (l0 <= cap_rel) ? 1u : 0u;     // mu = 0
+                copy_words<NW>(D, k0);
+            } else {
+                phase = PH_FAST;
+            }
             return;
         }
         copy_words<NW>(D, A);
@@ -203,16 +210,18 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
         }
 
         if constexpr (FAST_ONLY) {
-            // ---- lean iteration: probe the current state s(T_p + t) and compute s(T_p + t + 1) together
+            // ---- lean iteration: s(T_p + t + 1), then its probe (s(T_p) itself was probed at refill)
             uint32_t nxt[NW], l2 = 0, k2[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) k2[w] = 0;
-            const bool hit = cache_lookup<NW>(lc, cmask, vis, A, l2, k2);
+            uint32_t tag = 0;
             net_step<NW, K>(nv, A, fm0, fv0, nxt);
+            const bool hit = cache_lookup<NW>(lc, cmask, vis, nxt, l2, k2, &tag);
             if (phase == PH_FAST) {
                 ++exec32;
-                const bool ok = hit && t <= cap_rel && l2 <= cap_rel - t;       // mu + lambda <= max_t - T_p
-                const bool lost = !hit && t >= fast_steps;
+                const uint32_t t1 = t + 1;
+                const bool ok = hit && t1 <= cap_rel && l2 <= cap_rel - t1;     // mu + lambda <= max_t - T_p
+                const bool lost = !hit && t1 >= fast_steps;
                 if (lost) {
                     const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
                     if (at < P.stragglers_cap) P.stragglers[at] = (uint32_t)my_p;
@@ -222,9 +231,10 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
 #pragma unroll
                 for (int w = 0; w < NW; ++w) { D[w] = hit ? k2[w] : D[w]; A[w] = nxt[w]; }
                 lam = l2;
-                cnt = ok ? t : 0u;
+                pub = tag;
+                cnt = ok ? t1 : 0u;
                 sub = ok ? 1u : 0u;
-                ++t;
+                t = t1;
                 phase = hit ? PH_DONE : (lost ? PH_IDLE : PH_FAST);
             }
             continue;
