@@ -473,6 +473,7 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec
     HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu wave-iterations (%llu service rounds), lane utilisation %.3f, %.3f ms\n", fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec, (unsigned long long)run.ctr.wave_iters, (unsigned long long)run.ctr.service_rounds, run.ctr.wave_iters ? (double)run.ctr.steps_exec / (64.0 * (double)(run.ctr.wave_iters - run.ctr.service_rounds)) : 0.0, run.ms);
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
     if (!merged) return BSX_OK;
     const uint64_t n_log = run.ctr.log_cursor;

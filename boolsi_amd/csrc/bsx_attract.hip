@@ -30,7 +30,9 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     const bool simple_space = FAST_ONLY || (P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv);
     const bool use_cache = FAST_ONLY || P.cc.enabled != 0;
     const uint32_t fast_steps = P.fast_steps;
-    const uint32_t service_lanes = P.pad ? P.pad : kServiceLanes;
+    // lanes that must be waiting before a service round is worth its cost (measured: the lean kernel
+    // is fastest when most of the wave is served at once, profiles/r01_pmc.md)
+    const uint32_t service_lanes = P.pad ? P.pad : (FAST_ONLY ? 48u : kServiceLanes);
     const uint32_t cmask = P.cc.lds_slots - 1;
 
     // LDS mirror of the cycle-state cache (pointer arithmetic on `smem` keeps the LDS address space:
@@ -75,12 +77,19 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     uint32_t ck[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) ck[w] = 0;
+    // Accumulators are 32-bit in the lean kernel: there T_p = 0 and mu <= fast_steps, and a lane sees
+    // at most count / (lanes in flight) problems, so the per-lane sums stay far below 2^32.
+    using acc_t = typename std::conditional<FAST_ONLY, uint32_t, uint64_t>::type;
+    constexpr acc_t kSqGuard = FAST_ONLY ? (acc_t)0x7FFF0000u : (acc_t)(1ull << 62);
     uint32_t clen = 0, ccnt = 0;
-    uint64_t csl = 0, csl2 = 0;
+    acc_t csl = 0, csl2 = 0;
 
-    uint64_t steps_ref = 0, steps_exec = 0;
-    uint32_t n_none = 0, limit_hits = 0;
+    acc_t steps_ref = 0, steps_exec = 0;       // steps_ref: found problems only; the others add max_t each
+    uint32_t n_none = 0, n_capfail = 0, limit_hits = 0;
 
+#ifdef BSX_DIAG
+    unsigned long long dbg_iters = 0, dbg_service = 0;
+#endif
     WaveQueue q{0, 0, true};
     if constexpr (FAST_ONLY) vis = cache_visible(lc);      // static for the launch: nobody inserts
 
@@ -118,8 +127,12 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
         const uint32_t n_wait = 64u - n_run;                       // pending + idle
         const bool work_left = q.more || q.next < q.end;
         if (n_run == 0 && n_pend == 0 && !work_left) break;
-        const bool service = (n_pend && (n_pend >= kServiceLanes || n_run == 0 || !work_left)) ||
-                             (work_left && (n_wait >= kServiceLanes || n_run == 0));
+        const bool service = (n_pend && (n_pend >= service_lanes || n_run == 0 || !work_left)) ||
+                             (work_left && (n_wait >= service_lanes || n_run == 0));
+#ifdef BSX_DIAG
+        ++dbg_iters;
+        if (service) ++dbg_service;
+#endif
         if (service) {
             // ---- resolved problems: statistics, per-problem record, aggregation
             bool flush = false, want_pub = false;
@@ -131,10 +144,11 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                 phase = PH_IDLE;
                 const bool found = sub != 0;
                 const uint32_t traj32 = tp + cnt;
-                const uint64_t traj_l = traj32;
+                const acc_t traj_l = traj32;
                 steps_exec += exec32;
                 // reference loop stops at T_p + mu + lambda when found, at max_t otherwise (model.py:201)
-                steps_ref += found ? (uint64_t)(traj32 + lam) : (P.cap_rel_inf ? 0ull : P.max_t);
+                steps_ref += found ? (acc_t)(traj32 + lam) : (acc_t)0;
+                n_capfail += found ? 0u : 1u;
                 const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
                 want_pub = found && pub && use_cache && lam <= kCycleCacheMaxLen;
                 if (P.per_problem) {
@@ -148,9 +162,9 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                     r.length = keep ? lam : 0; r.trajectory_l = keep ? traj32 : 0; r.found = keep; r.pad = 0;
                     P.per_problem[my_p] = r;
                 }
-                const uint64_t sq = (uint64_t)traj32 * traj32;
+                const acc_t sq = (acc_t)traj32 * traj32;
                 if (!keep) ++n_none;
-                else if (ccnt && eq_words<NW>(ck, D) && csl2 < (1ull << 62)) { ++ccnt; csl += traj_l; csl2 += sq; }
+                else if (ccnt && eq_words<NW>(ck, D) && csl2 < kSqGuard) { ++ccnt; csl += traj_l; csl2 += sq; }
                 else {
                     if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
                     copy_words<NW>(ck, D); clen = lam; ccnt = 1; csl = traj_l; csl2 = sq;
@@ -331,7 +345,11 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     // ---- epilogue: lane caches -> wave table -> HBM log; counters
     table_merge<NW>(P, slot, lane, ccnt != 0, ck, clen, ccnt, csl, csl2);
     if (slot.count) log_append<NW>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
-    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_ref);
+#ifdef BSX_DIAG
+    if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_service); }
+#endif
+    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_ref +
+                                     (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t));
     atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps_exec);
     if (n_none) atomicAdd(&P.ctr->n_none, (unsigned long long)n_none);
     if (limit_hits) atomicAdd(&P.ctr->step_limit_hits, limit_hits);

@@ -78,6 +78,8 @@ struct Counters {               // zeroed before every launch
     unsigned long long n_stragglers;    // fast kernel: problems handed to the general kernel
     unsigned int straggler_overflow;
     unsigned int pad;
+    unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
+    unsigned long long service_rounds;  // diagnostic
 };
 
 // Cache of known cycle states (DESIGN.md "cycle-state cache").  A trajectory enters its attractor at

@@ -18,6 +18,7 @@
 // 52-73, warm-up 76-128, detection loop 152-236, solvers attract.py:262-302 / target.py:109-133 /
 // simulate.py:97-131, store_attractor attract.py:374-402, problem enumeration batching.py:160-282.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bsx_device.h"
 
 namespace bsx {
