@@ -84,6 +84,15 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     uint32_t clen = 0, ccnt = 0;
     acc_t csl = 0, csl2 = 0;
 
+    // Lean kernel: results of the first kTagAcc cached attractors are summed per lane by tag with
+    // predicated adds (no key compare, no cross-lane merge until the kernel ends); consecutive problems
+    // alternate between a few attractors, and flushing the one-entry run cache on every change was the
+    // dominant cost of a service round.
+    constexpr int kTagAcc = 3;
+    uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
+#pragma unroll
+    for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
+
     acc_t steps_ref = 0, steps_exec = 0;       // steps_ref: found problems only; the others add max_t each
     uint32_t n_none = 0, n_capfail = 0, limit_hits = 0;
 
@@ -163,7 +172,19 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                     P.per_problem[my_p] = r;
                 }
                 const acc_t sq = (acc_t)traj32 * traj32;
+                bool by_tag = false;
+                if constexpr (FAST_ONLY) {
+                    by_tag = keep && pub <= (uint32_t)kTagAcc;
+#pragma unroll
+                    for (int j = 0; j < kTagAcc; ++j) {
+                        const bool m = by_tag && pub == (uint32_t)(j + 1);
+                        tcnt[j] += m ? 1u : 0u;
+                        tsl[j] += m ? traj32 : 0u;
+                        tsl2[j] += m ? (uint32_t)sq : 0u;
+                    }
+                }
                 if (!keep) ++n_none;
+                else if (by_tag) {}
                 else if (ccnt && eq_words<NW>(ck, D) && csl2 < kSqGuard) { ++ccnt; csl += traj_l; csl2 += sq; }
                 else {
                     if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
@@ -343,6 +364,27 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     }
 
     // ---- epilogue: lane caches -> wave table -> HBM log; counters
+    if constexpr (FAST_ONLY) {
+        // per-tag sums -> wave table: key and length of tag j + 1 from any of its mirror entries
+        constexpr int S = CacheLayout<NW>::kStride;
+        const uint32_t* base = lc + kCacheHeaderWords;
+#pragma unroll
+        for (int j = 0; j < kTagAcc; ++j) {
+            if (!__ballot(tcnt[j] != 0)) continue;
+            uint32_t k[NW], len = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) k[w] = 0;
+            for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
+                if (base[sl * S + NW] == (uint32_t)(j + 1)) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) k[w] = base[sl * S + NW + 2 + w];
+                    len = base[sl * S + NW + 1];
+                    break;
+                }
+            }
+            table_merge<NW>(P, slot, lane, tcnt[j] != 0, k, len, tcnt[j], (uint64_t)tsl[j], (uint64_t)tsl2[j]);
+        }
+    }
     table_merge<NW>(P, slot, lane, ccnt != 0, ck, clen, ccnt, csl, csl2);
     if (slot.count) log_append<NW>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
 #ifdef BSX_DIAG
