@@ -38,13 +38,20 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     // LDS mirror of the cycle-state cache (pointer arithmetic on `smem` keeps the LDS address space:
     // a round trip through an integer would turn every probe into a flat load)
     uint32_t* lc = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);
+    // lean kernel: workgroup accumulators (LDS atomics) for cached attractors kTagAcc+1 .. kTagAcc+kLdsAcc
+    const uint32_t lc_words = kCacheHeaderWords + P.cc.lds_slots * CacheLayout<NW>::kStride;
+    unsigned long long* acc_sl2 = reinterpret_cast<unsigned long long*>(lc + ((lc_words + 1u) & ~1u));
+    unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl2 + kLdsAcc);
+    unsigned int* acc_sl = acc_cnt + kLdsAcc;
     uint32_t cc_seen = 0, cc_states = 0, cc_attr = 0, cc_rounds = 0;       // meaningful in thread 0 only
     uint32_t fm0[NW], fv0[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; }
     if (use_cache) {
-        for (uint32_t i = threadIdx.x; i < kCacheHeaderWords + P.cc.lds_slots * CacheLayout<NW>::kStride; i += blockDim.x)
-            lc[i] = 0;
+        for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
+        if constexpr (FAST_ONLY) {
+            for (uint32_t i = threadIdx.x; i < kLdsAcc; i += blockDim.x) { acc_sl2[i] = 0; acc_cnt[i] = 0; acc_sl[i] = 0; }
+        }
         __syncthreads();
         if (threadIdx.x == 0) cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
         __syncthreads();
@@ -88,7 +95,6 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     // predicated adds (no key compare, no cross-lane merge until the kernel ends); consecutive problems
     // alternate between a few attractors, and flushing the one-entry run cache on every change was the
     // dominant cost of a service round.
-    constexpr int kTagAcc = 3;
     uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
 #pragma unroll
     for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
@@ -185,6 +191,11 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                 }
                 if (!keep) ++n_none;
                 else if (by_tag) {}
+                else if constexpr (FAST_ONLY) {         // attractors beyond the register accumulators
+                    atomicAdd(&acc_cnt[pub - 1 - kTagAcc], 1u);
+                    atomicAdd(&acc_sl[pub - 1 - kTagAcc], traj32);
+                    atomicAdd(&acc_sl2[pub - 1 - kTagAcc], (unsigned long long)sq);
+                }
                 else if (ccnt && eq_words<NW>(ck, D) && csl2 < kSqGuard) { ++ccnt; csl += traj_l; csl2 += sq; }
                 else {
                     if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
@@ -383,6 +394,21 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                 }
             }
             table_merge<NW>(P, slot, lane, tcnt[j] != 0, k, len, tcnt[j], (uint64_t)tsl[j], (uint64_t)tsl2[j]);
+        }
+        // workgroup accumulators -> HBM log, one thread per attractor
+        __syncthreads();
+        for (uint32_t a = threadIdx.x; a < kLdsAcc; a += blockDim.x) {
+            const uint32_t cn = acc_cnt[a];
+            if (!cn) continue;
+            for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
+                if (base[sl * S + NW] == a + 1 + kTagAcc) {
+                    uint32_t k[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) k[w] = base[sl * S + NW + 2 + w];
+                    log_append<NW>(P, k, base[sl * S + NW + 1], cn, (uint64_t)acc_sl[a], (uint64_t)acc_sl2[a]);
+                    break;
+                }
+            }
         }
     }
     table_merge<NW>(P, slot, lane, ccnt != 0, ck, clen, ccnt, csl, csl2);

@@ -449,6 +449,10 @@ __device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]) {
 // LDS mirror: word 0 of the header = number of attractors whose states are all inserted ("visible");
 // an entry's tag is the 1-based sequence number of its attractor and counts only when <= visible.
 constexpr int kCacheHeaderWords = 4;
+// Lean attract kernel: results of cached attractors 1..kTagAcc are summed in registers per lane,
+// kTagAcc+1 .. kTagAcc+kLdsAcc in per-workgroup LDS accumulators; later ones are left to the detector.
+constexpr int kTagAcc = 3;
+constexpr uint32_t kLdsAcc = 128;
 
 // One probe: loads the whole entry with no control flow in between (so the reads are issued together
 // with whatever else the caller has in flight) and classifies it.
