@@ -446,7 +446,8 @@ struct KeyLess {
 namespace {
 
 constexpr uint64_t kFastMinProblems = 8192;     // below this the general kernel alone is used
-constexpr uint64_t kDiscoveryPrefix = 65536;    // problems run through the detector when no attractor is cached yet
+constexpr uint64_t kDiscoverySample = 65536;    // problems (sampled over the range) run through the detector when nothing is cached yet
+constexpr uint64_t kLeanTile = 1ull << 28;      // problems per lean-kernel launch (straggler list: 4 B each)
 constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps without a cached cycle state)
 
 using MergedTable = std::map<std::vector<uint32_t>, bsx_attr_rec, KeyLess>;
@@ -560,66 +561,65 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
 
     // Fast path: simple enumeration (no variations, 'any' nodes = nodes 0..a-1, a <= 64), no warm-up,
     // cycle cache on.  [discovery prefix with the detector] -> lean kernel -> stragglers.
-    const bool simple = h->sp.identity_any && h->sp.n_any <= 64 && !h->sp.n_fv && !h->sp.n_pv && !h->sp.tp_origin;
+    // (a short uniform warm-up is fine; its length enters the lean kernel's 32-bit sums of trajectory_l^2)
+    const bool simple = h->sp.identity_any && h->sp.n_any <= 64 && !h->sp.n_fv && !h->sp.n_pv && h->sp.tp_origin <= 200;
     bool use_fast = P.cc.enabled && simple && h->fast_ok && count >= kFastMinProblems;
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] attract: count %llu cache %u identity %u n_any %u n_fv %u n_pv %u tp %u fast_ok %d -> lean path %d\n", (unsigned long long)count, P.cc.enabled, h->sp.identity_any, h->sp.n_any, h->sp.n_fv, h->sp.n_pv, h->sp.tp_origin, (int)h->fast_ok, (int)use_fast);
     uint64_t done = 0;
     if (use_fast) {
         unsigned int known = 0;
         HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
         if (known == 0) {
+            // Nothing cached yet: run the detector over a pseudo-random sample of the range (all digit
+            // positions vary), only to fill the cycle cache; its results are discarded and every problem
+            // is counted exactly once below.
+            const uint64_t m = std::min<uint64_t>(count, kDiscoverySample);
+            std::vector<uint32_t> sample(m);
+            for (uint64_t i = 0; i < m; ++i) {
+                uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;        // splitmix64 finaliser
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                sample[i] = (uint32_t)((z ^ (z >> 31)) % count);
+            }
+            DevBuf<uint32_t> d_sample;
+            HIPCHK(h, d_sample.upload(sample));
             AttractParams Q = P;
-            Q.count = std::min<uint64_t>(count, kDiscoveryPrefix);
+            Q.count = m;
+            Q.offsets = d_sample.p;
+            Q.per_problem = nullptr;
             AttractRun r;
-            if (int rc = launch_attract_pass(h, Q, false, d_log, &merged, r)) return rc;
-            account(r);
-            done = Q.count;
+            if (int rc = launch_attract_pass(h, Q, false, d_log, nullptr, r)) return rc;
+            kernel_ms += r.ms; ++launches; steps_exec += r.ctr.steps_exec;
             HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
             if (known == 0) use_fast = false;           // nothing cacheable was found
         }
     }
-    if (use_fast && done < count) {
-        const uint64_t rest = count - done;
+    // Lean kernel over tiles; what it cannot resolve (attractors not cached yet, long transients) goes
+    // through the detector right after each tile, which also teaches the cache for the next tile.
+    while (use_fast && h->fast_ok && done < count) {
+        const uint64_t tile = std::min<uint64_t>(count - done, kLeanTile);
         DevBuf<uint32_t>& d_strag = h->d_strag;
-        const uint64_t strag_cap = rest / 4 + 4096;
-        if (d_strag.n < strag_cap) HIPCHK(h, d_strag.alloc(strag_cap));
+        if (d_strag.n < tile) HIPCHK(h, d_strag.alloc(tile));
         AttractParams Q = P;
         advance_first(Q.sp, first, done);
-        Q.count = rest;
+        Q.count = tile;
         Q.per_problem = per_problem ? d_pp.p + done : nullptr;
         Q.stragglers = d_strag.p;
-        Q.stragglers_cap = strag_cap;
-        MergedTable fast_merged;
+        Q.stragglers_cap = tile;
         AttractRun r;
-        if (int rc = launch_attract_pass(h, Q, true, d_log, &fast_merged, r)) return rc;
-        if (r.ctr.straggler_overflow) {
-            // the cache does not cover this space: drop the lean pass, remember, use the detector
-            h->fast_ok = false;
-            kernel_ms += r.ms; ++launches;
-            steps_exec += r.ctr.steps_exec;
-        } else {
-            account(r);
-            for (auto& kv : fast_merged) {
-                auto it = merged.find(kv.first);
-                if (it == merged.end()) merged.emplace(kv.first, kv.second);
-                else {
-                    bsx_attr_rec& a = it->second;
-                    a.count += kv.second.count; a.sum_l += kv.second.sum_l;
-                    const uint64_t lo = a.sum_l2_lo + kv.second.sum_l2_lo;
-                    a.sum_l2_hi += kv.second.sum_l2_hi + (lo < a.sum_l2_lo ? 1 : 0);
-                    a.sum_l2_lo = lo;
-                }
-            }
-            if (r.ctr.n_stragglers) {
-                AttractParams S = Q;
-                S.count = r.ctr.n_stragglers;
-                S.offsets = d_strag.p;
-                S.stragglers = nullptr;
-                AttractRun rs;
-                if (int rc = launch_attract_pass(h, S, false, d_log, &merged, rs)) return rc;
-                account(rs);
-            }
-            done = count;
+        if (int rc = launch_attract_pass(h, Q, true, d_log, &merged, r)) return rc;
+        account(r);
+        if (r.ctr.n_stragglers) {
+            AttractParams S = Q;
+            S.count = r.ctr.n_stragglers;
+            S.offsets = d_strag.p;
+            S.stragglers = nullptr;
+            AttractRun rs;
+            if (int rc = launch_attract_pass(h, S, false, d_log, &merged, rs)) return rc;
+            account(rs);
         }
+        done += tile;
+        if (r.ctr.n_stragglers > tile / 2) h->fast_ok = false;    // the cache does not cover this space
     }
     if (done < count) {
         AttractParams Q = P;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     uint32_t* smem_free;
     const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
-    const bool has_warmup = !FAST_ONLY && (P.sp.tp_origin | P.sp.n_pv) != 0;       // wave-uniform
+    const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
     const bool simple_space = FAST_ONLY || (P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv);
     const bool use_cache = FAST_ONLY || P.cc.enabled != 0;
     const uint32_t fast_steps = P.fast_steps;
@@ -262,6 +262,13 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
             for (int w = 0; w < NW; ++w) k2[w] = 0;
             uint32_t tag = 0;
             net_step<NW, K>(nv, A, fm0, fv0, nxt);
+            if (has_warmup && phase == PH_WARM) {       // uniform origin schedule only (no variations here)
+                ++t; ++exec32;
+                apply_perturbations<NW>(P.sp, t, 0ull, nxt);
+                copy_words<NW>(A, nxt);
+                if (t == tp) begin_search();
+                continue;
+            }
             const bool hit = cache_lookup<NW>(lc, cmask, vis, nxt, l2, k2, &tag);
             if (phase == PH_FAST) {
                 ++exec32;
