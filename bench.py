@@ -129,7 +129,7 @@ def main():
             'n_attractors': n_attractors,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_attract<2,2,lds>', 'avg_launch_ms': avg_launch_s * 1e3,
+                         'kernel': 'k_attract<NW=2,K=2,LDS,lean>', 'avg_launch_ms': avg_launch_s * 1e3,
                          'alg_bytes_per_launch': alg_bytes_per_launch},
         }
         if comm.world == 1 and not args.no_cpu_baseline:
