@@ -3,10 +3,13 @@ Command line: `python -m boolsi_amd simulate|attract|target FILE [options]`, sam
 option names as the reference's `boolsi` script (`boolsi/cli.py:35-63, 184-328`).
 
 Differences, all outside the hot path: results are kept in memory instead of a ZODB spill
-(`-d`, `-k` accepted and ignored); `-b` is accepted and ignored (the GPU dequeues its own chunks);
-graphic outputs are not produced (`--no-pdf` is implied, `--print-*` warn).  Under
-`torch.distributed.run` every rank drives one GPU and `attract` range-partitions the problems
-(boolsi_amd/dist.py); simulate / target use rank 0's GPU only.
+(`-d`, `-k` accepted and ignored); `-b` does not schedule anything (the GPU dequeues its own chunks),
+it only shapes the listing order under `--reference-np`; graphic outputs are not produced (`--no-pdf`
+is implied, `--print-*` warn).  Under `torch.distributed.run` every rank drives one GPU and all three
+commands range-partition the problems (boolsi_amd/dist.py); rank 0 writes the output.
+`--reference-np P` lists the simulations of simulate / target in the order a reference run under
+`mpiexec -np P` (P - 1 workers, `-b` batches each) writes them (batching.BatchLayout); the default is
+the single-process order = problem-index order.
 Error policy as the reference (cli.py:138-151,181): input / engine errors are logged and the
 process terminates normally.
 """
@@ -31,7 +34,10 @@ def _common(f):
         click.option('-o', '--output-directory', type=click.Path(file_okay=False), default='output_' + _timestamp,
                      help='Directory to print output to. Defaults to "<current directory>/output_<timestamp>".'),
         click.option('-b', '--batches-per-process', type=click.IntRange(min=1, max=2 ** 31), default=100,
-                     help='Accepted for compatibility; the GPU engine schedules its own chunks.'),
+                     help='Batches per process of the reference run whose listing order --reference-np reproduces; '
+                          'the GPU engine schedules its own chunks.'),
+        click.option('--reference-np', type=click.IntRange(min=1), default=1,
+                     help='List simulations in the order of a reference run under "mpiexec -np N" (default 1).'),
         click.option('-d', '--tmp-database-directory', 'db_dir', type=click.Path(file_okay=False), default='tmp_db',
                      help='Accepted for compatibility; results are kept in memory.'),
         click.option('--no-pdf', is_flag=True, help='PDF output is not available in this build (always off).'),
@@ -102,6 +108,14 @@ def _guarded(kw, body):
     run.finish()
 
 
+def _listing(kw, cfg):
+    """Listing order of a multi-process reference run, or None for index order."""
+    if kw['reference_np'] <= 2:      # no workers, or one worker: one chunk, stride 1
+        return None
+    from .batching import batch_layout
+    return batch_layout(cfg['total combination count'], kw['reference_np'], kw['batches_per_process'])
+
+
 @click.group()
 def cli():
     """BoolSi-compatible simulations of synchronous Boolean networks on AMD MI355X GPUs."""
@@ -115,13 +129,13 @@ def simulate(**kw):
     def body(run):
         from .simulate import simulate_master
         from .output import output_simulations
-        if run.comm.rank != 0:
-            return
         cfg = process_input(kw['input_file'], run.out, kw['simulation_time'], Mode.SIMULATE)
         sims = simulate_master(run.open_engine(), cfg['origin simulation problem'],
                                cfg['simulation problem variations'], cfg['incoming node lists'],
-                               cfg['truth tables'], kw['simulation_time'], cfg['total combination count'])
-        output_simulations(sims, cfg['node names'], run.out)
+                               cfg['truth tables'], kw['simulation_time'], cfg['total combination count'],
+                               comm=run.comm, listing=_listing(kw, cfg))
+        if run.comm.rank == 0:
+            output_simulations(sims, cfg['node names'], run.out)
     _guarded(kw, body)
 
 
@@ -185,16 +199,15 @@ def target(**kw):
     def body(run):
         from .target import target_master
         from .output import output_simulations
-        if run.comm.rank != 0:
-            return
         max_t = kw['max_simulation_time'] or inf
         n_to_find = kw['n_simulations_reaching_target'] or inf
         cfg = process_input(kw['input_file'], run.out, max_t, Mode.TARGET)
         sims = target_master(run.open_engine(), cfg['origin simulation problem'],
                              cfg['simulation problem variations'], cfg['target substate code'],
                              cfg['target node set'], cfg['incoming node lists'], cfg['truth tables'],
-                             n_to_find, max_t, cfg['total combination count'])
-        if sims:
+                             n_to_find, max_t, cfg['total combination count'],
+                             comm=run.comm, listing=_listing(kw, cfg))
+        if sims and run.comm.rank == 0:
             output_simulations(sims, cfg['node names'], run.out)
     _guarded(kw, body)
 

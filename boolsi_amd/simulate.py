@@ -39,10 +39,20 @@ def states_from_words(traj, n_nodes):
 
 
 def simulate_master(engine, origin_simulation_problem, simulation_problem_variations,
-                    predecessor_node_lists, truth_tables, max_t, n_simulation_problems):
-    """-> list of Simulation in problem-index order (single process enumeration order)."""
-    logging.getLogger().info('Single process will be used to perform {} simulations...'.format(
-        n_simulation_problems))
+                    predecessor_node_lists, truth_tables, max_t, n_simulation_problems, comm=None, listing=None):
+    """
+    -> list of Simulation (on rank 0; other ranks get []).  Order: problem-index order, which is the
+    order of a single-process reference run; with `listing` (batching.BatchLayout) the order in which a
+    multi-process reference run with that layout lists them (batch number, place in batch).
+    With more than one rank the index range is partitioned and the trajectories all-gathered.
+    """
+    from .dist import Comm, partition
+    comm = comm or Comm()
+    log = logging.getLogger()
+    if comm.world == 1:
+        log.info('Single process will be used to perform {} simulations...'.format(n_simulation_problems))
+    else:
+        log.info('{} GPUs will be used to perform {} simulations...'.format(comm.world, n_simulation_problems))
     n_nodes = len(predecessor_node_lists)
     if n_simulation_problems * (max_t + 1) * n_nodes > MAX_STATE_CELLS:
         raise ValueError(
@@ -52,15 +62,24 @@ def simulate_master(engine, origin_simulation_problem, simulation_problem_variat
     net = compile_network(predecessor_node_lists, truth_tables)
     space = compile_space(origin_simulation_problem, simulation_problem_variations)
     engine.set_problem(net, space)
-    numeral_system = create_numeral_system_from_variations(simulation_problem_variations)
-    simulations = []
-    for first in range(0, n_simulation_problems, TILE):
-        count = min(TILE, n_simulation_problems - first)
+    lo, mine = partition(n_simulation_problems, comm.world, comm.rank)
+    parts = []
+    for first in range(lo, lo + mine, TILE):
+        count = min(TILE, lo + mine - first)
         traj, _, _, _ = engine.simulate(first, count, max_t, trajectories=True, final=False, digest=False)
-        for q in range(count):
-            _, fixed_nodes, perturbed_nodes_by_t = problem_from_index(
-                first + q, origin_simulation_problem, simulation_problem_variations, numeral_system)
-            simulations.append(Simulation(states_from_words(traj[q], n_nodes), fixed_nodes, perturbed_nodes_by_t))
+        parts.append(traj)
+    local = np.concatenate(parts) if parts else np.zeros((0, max_t + 1, net.n_words), np.uint64)
+    trajs = comm.gather_concat(local)
+    if comm.rank != 0:
+        return []
+    numeral_system = create_numeral_system_from_variations(simulation_problem_variations)
+    from .batching import reference_order
+    order = reference_order(listing) if listing is not None else range(n_simulation_problems)
+    simulations = []
+    for index in order:
+        _, fixed_nodes, perturbed_nodes_by_t = problem_from_index(
+            index, origin_simulation_problem, simulation_problem_variations, numeral_system)
+        simulations.append(Simulation(states_from_words(trajs[index], n_nodes), fixed_nodes, perturbed_nodes_by_t))
     return simulations
 
 

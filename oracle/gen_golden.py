@@ -418,9 +418,100 @@ def gen_enumeration():
                                'problems': [problem_json(problem_of(cfg, i)) for i in idx]})
 
 
+def index_of_digits(digits, radices):
+    value, place = 0, 1
+    for d, r in zip(digits, radices):
+        value += d * place
+        place *= r
+    return value
+
+
+def gen_batch_seeds():
+    """Batch seeds and per-batch problem order (batching.py:79-157, 255-282) -- what decides the order in
+    which a reference run with P processes / B batches per process lists its simulations."""
+    b = R['batching']
+    names = sorted(RULES_B)
+    spaces = {
+        'binary': toy_yaml(RULES_B, initial='any'),
+        'mixed': toy_yaml(RULES_B, initial={n: ('any' if i < 3 else '1') for i, n in enumerate(names)},
+                          fixed={names[4]: 'any?', names[5]: '0?'},
+                          perturbations={names[3]: {'any?': '2', '1?': '4'}}),
+    }
+    cases = []
+    for space, text in spaces.items():
+        cfg = parse_text(text, 'simulate', 6)
+        n = cfg['total combination count']
+        variations = cfg['simulation problem variations']
+        for n_chunks, n_batches in [(1, 1), (1, 100), (1, 7), (2, 3), (3, 5), (4, 4), (5, 2), (6, 3), (7, 100),
+                                    (8, 1), (9, 2), (12, 5), (63, 100), (n, 1), (n + 3, 2)]:
+            seeds = list(b.generate_simulation_problem_batch_seeds(variations, n_chunks, n, n_batches))
+            batches = []
+            for first, size, inc, radices in seeds:
+                digits, order = list(first), []
+                for _ in range(size):
+                    order.append(index_of_digits(digits, radices))
+                    digits = b.add_variational_representations(digits, inc, radices)
+                batches.append({'first': list(first), 'size': size, 'increment': list(inc), 'radices': list(radices),
+                                'order': order})
+            cases.append({'space': space, 'n_chunks': n_chunks, 'batches_per_chunk': n_batches,
+                          'n_batches_counted': b.count_simulation_problem_batches(n_chunks, n, n_batches),
+                          'increment': b.calculate_increment_for_chunking_simulation_problems(n, n_chunks),
+                          'batches': batches})
+    # the problems themselves, in batch order, for one multi-process shape (labels + initial states)
+    cfg = parse_text(spaces['mixed'], 'simulate', 6)
+    listed = []
+    for task in b.generate_tasks(cfg['origin simulation problem'], cfg['simulation problem variations'],
+                                 cfg['incoming node lists'], cfg['truth tables'], 3,
+                                 cfg['total combination count'], 5):
+        listed.append([problem_json(p) for p in b.generate_simulation_problems(*task[0])])
+    write('batch_seeds.json', {'yaml': spaces, 'max_t': 6, 'cases': cases,
+                               'listed': {'space': 'mixed', 'n_chunks': 3, 'batches_per_chunk': 5, 'batches': listed}})
+
+
+def listing_case(mode, text, max_t, n_processes, batches_per_process):
+    """Simulations in the order a reference run with `n_processes` MPI processes stores them: tasks of
+    batching.generate_tasks through mpi.execute_task, keyed (batch number, place in batch) as
+    simulate.write_simulations_to_db:166-168 does."""
+    from functools import partial
+    cfg = parse_text(text, mode, max_t)
+    n = cfg['total combination count']
+    n_chunks = max(n_processes - 1, 1)
+    if mode == 'simulate':
+        solve = R['mpi'].configure_solve_simulation_problem(
+            partial(R['simulate'].simulate_until_max_t, max_t), True, max_t, set(), None)
+    else:
+        solve = R['mpi'].configure_solve_simulation_problem(
+            R['target'].simulate_until_target_substate_or_max_t, True, max_t,
+            cfg['target node set'], cfg['target substate code'])
+    listed = []
+    for task in R['batching'].generate_tasks(
+            cfg['origin simulation problem'], cfg['simulation problem variations'], cfg['incoming node lists'],
+            cfg['truth tables'], n_chunks, n, batches_per_process):
+        _, simulations = R['mpi'].execute_task(task, solve, R['simulate'].store_simulation, [], inf)
+        for sim in simulations:
+            listed.append({'states': [str(code_of(st)) for st in sim.states],
+                           'fixed': sorted([int(k), int(v)] for k, v in sim.fixed_nodes.items()),
+                           'pert': sorted([int(t), int(k), int(v)] for t, d in sim.perturbed_nodes_by_t.items()
+                                          for k, v in d.items())})
+    return {'mode': mode, 'yaml': text, 'max_t': max_t, 'np': n_processes, 'b': batches_per_process,
+            'n_problems': n, 'simulations': listed}
+
+
+def gen_listing():
+    names = sorted(RULES_B)
+    sim_text = toy_yaml(RULES_B, initial={n: ('any' if i < 3 else '1') for i, n in enumerate(names)},
+                        fixed={names[4]: 'any?', names[5]: '0?'}, perturbations={names[3]: {'any?': '2', '1?': '4'}})
+    tgt_text = toy_yaml(RULES_B, initial='any', fixed={names[1]: '0?'},
+                        target={n: ('1' if i == 0 else 'any') for i, n in enumerate(names)})
+    cases = [listing_case('simulate', sim_text, 6, 4, 5), listing_case('simulate', sim_text, 6, 8, 100),
+             listing_case('simulate', read_example('example1.yaml'), 5, 3, 2),
+             listing_case('target', tgt_text, 12, 5, 3), listing_case('target', tgt_text, 12, 1, 100)]
+    write('listing.json', cases)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['toy', 'examples', 'synth', 'target', 'simulate', 'input', 'enum']
+    which = sys.argv[1:] or ['toy', 'examples', 'synth', 'target', 'simulate', 'input', 'enum', 'seeds', 'listing']
     if 'toy' in which:
         gen_attract_toy()
     if 'examples' in which:
@@ -435,3 +526,7 @@ if __name__ == '__main__':
         gen_input()
     if 'enum' in which:
         gen_enumeration()
+    if 'seeds' in which:
+        gen_batch_seeds()
+    if 'listing' in which:
+        gen_listing()

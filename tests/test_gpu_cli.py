@@ -92,3 +92,64 @@ def test_input_error_is_logged_not_raised(tmp_path):
     path.write_text('nodes: [A]\nupdate rules: {A: B}\ninitial state: {A: any}\n')
     out = run_cli(['simulate', str(path), '-t', '3'], str(tmp_path / 'out'))
     assert 'ERROR Input validation failed' in out and "Unknown expression 'B'" in out and 'Bye!' in out
+
+
+# ----------------------------------------------------------------------------- multi-process listing order (f-2)
+
+def _sim_rows(sims):
+    from boolsi_amd.model import encode_state
+    return [{'states': [str(encode_state(set(), s)[0]) for s in sim.states],
+             'fixed': sorted([int(k), int(v)] for k, v in sim.fixed_nodes.items()),
+             'pert': sorted([int(t), int(k), int(v)] for t, d in sim.perturbed_nodes_by_t.items()
+                            for k, v in d.items())} for sim in sims]
+
+
+@pytest.mark.parametrize('case', load('listing.json'), ids=lambda c: '{}_np{}_b{}'.format(c['mode'], c['np'], c['b']))
+def test_listing_order_of_multi_process_reference_run(case):
+    """simulate_master / target_master with a BatchLayout list the simulations exactly as the reference's
+    task farm stores them (tests/golden/listing.json)."""
+    from math import inf
+    from boolsi_amd.batching import batch_layout
+    from boolsi_amd.constants import Mode
+    from boolsi_amd.engine import Engine
+    from boolsi_amd.input import parse_input_text
+    from boolsi_amd.simulate import simulate_master
+    from boolsi_amd.target import target_master
+    mode = {'simulate': Mode.SIMULATE, 'target': Mode.TARGET}[case['mode']]
+    cfg = parse_input_text(case['yaml'], case['max_t'], mode)
+    n = cfg['total combination count']
+    assert n == case['n_problems']
+    listing = batch_layout(n, case['np'], case['b']) if case['np'] > 2 else None
+    engine = Engine(0)
+    try:
+        if case['mode'] == 'simulate':
+            sims = simulate_master(engine, cfg['origin simulation problem'], cfg['simulation problem variations'],
+                                   cfg['incoming node lists'], cfg['truth tables'], case['max_t'], n,
+                                   listing=listing)
+        else:
+            sims = target_master(engine, cfg['origin simulation problem'], cfg['simulation problem variations'],
+                                 cfg['target substate code'], cfg['target node set'], cfg['incoming node lists'],
+                                 cfg['truth tables'], inf, case['max_t'], n, listing=listing)
+    finally:
+        engine.close()
+    assert _sim_rows(sims) == case['simulations']
+
+
+def test_cli_reference_np_changes_order_only(tmp_path):
+    case = next(c for c in load('listing.json') if c['mode'] == 'simulate' and c['np'] == 4)
+    path = tmp_path / 'net.yaml'
+    path.write_text(case['yaml'])
+    run_cli(['simulate', str(path), '-t', str(case['max_t'])], str(tmp_path / 'a'))
+    run_cli(['simulate', str(path), '-t', str(case['max_t']), '--reference-np', '4', '-b', '5'], str(tmp_path / 'b'))
+    a = read(tmp_path / 'a' / 'simulations.csv').split(b'\n')
+    b = read(tmp_path / 'b' / 'simulations.csv').split(b'\n')
+    assert a != b and len(a) == len(b)
+    # same simulations, renumbered: compare the multiset of per-simulation row blocks without the name column
+    def blocks(lines):
+        out = {}
+        for line in lines[1:]:
+            if line:
+                name, rest = line.split(b',', 1)
+                out.setdefault(name, []).append(rest)
+        return sorted(map(tuple, out.values()))
+    assert blocks(a) == blocks(b)

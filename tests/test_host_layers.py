@@ -140,3 +140,56 @@ def test_cli_surface():
         for flag in flags + ['-o', '-b', '-d', '--no-pdf', '--no-csv', '--print-png', '--print-svg']:
             assert flag in out, (cmd, flag)
     assert runner.invoke(cli, ['simulate', os.path.join(EXAMPLES, 'output2_example1', 'example1.yaml')]).exit_code != 0
+
+
+# ----------------------------------------------------------------------------- reference batch order (SURVEY f-2)
+
+def _batch_cases():
+    return load("batch_seeds.json")
+
+
+def test_batch_seeds_match_reference():
+    from boolsi_amd import batching
+    from boolsi_amd.input import parse_input_text
+    from boolsi_amd.constants import Mode
+    g = _batch_cases()
+    for case in g['cases']:
+        cfg = parse_input_text(g['yaml'][case['space']], g['max_t'], Mode.SIMULATE)
+        n = cfg['total combination count']
+        variations = cfg['simulation problem variations']
+        seeds = list(batching.generate_simulation_problem_batch_seeds(
+            variations, case['n_chunks'], n, case['batches_per_chunk']))
+        assert len(seeds) == len(case['batches']) == case['n_batches_counted'] == \
+            batching.count_simulation_problem_batches(case['n_chunks'], n, case['batches_per_chunk'])
+        assert batching.calculate_increment_for_chunking_simulation_problems(n, case['n_chunks']) == case['increment']
+        for (first, size, inc, radices), want in zip(seeds, case['batches']):
+            assert (first, size, inc, radices) == (want['first'], want['size'], want['increment'], want['radices'])
+        layout = batching.BatchLayout(n, case['n_chunks'], case['batches_per_chunk'])
+        order = batching.reference_order(layout)
+        assert order == [i for b in case['batches'] for i in b['order']]
+        assert sorted(order) == list(range(n))
+        # closed-form position == place in the listing
+        keys = [layout.position(i) for i in order]
+        assert keys == sorted(keys)
+        assert keys == [(bi, k) for bi, b in enumerate(case['batches']) for k in range(b['size'])]
+
+
+def test_reference_listing_labels():
+    """Problems of every batch (initial state, fixed nodes, perturbations) as the reference generates them."""
+    from boolsi_amd import batching
+    from boolsi_amd.input import parse_input_text
+    from boolsi_amd.constants import Mode
+    from boolsi_amd.model import encode_state
+    g = _batch_cases()
+    want = g['listed']
+    cfg = parse_input_text(g['yaml'][want['space']], g['max_t'], Mode.SIMULATE)
+    layout = batching.BatchLayout(cfg['total combination count'], want['n_chunks'], want['batches_per_chunk'])
+    got = list(batching.reference_order(layout))
+    flat = [p for b in want['batches'] for p in b]
+    assert len(got) == len(flat)
+    for index, p in zip(got, flat):
+        init, fixed, pert = batching.problem_from_index(index, cfg['origin simulation problem'],
+                                                        cfg['simulation problem variations'])
+        assert str(encode_state(set(), init)[0]) == p['initial_code']
+        assert sorted([n, int(v)] for n, v in fixed.items()) == p['fixed']
+        assert sorted([t, n, int(v)] for t, d in pert.items() for n, v in d.items()) == p['pert']
