@@ -37,7 +37,7 @@ class Comm:
         c.rank = int(os.environ.get('RANK', '0'))
         c.world = world
         c.local_rank = int(os.environ.get('LOCAL_RANK', c.rank))
-        c.backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        c.backend = backend or os.environ.get('BSX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if c.backend == 'nccl':
             torch.cuda.set_device(c.local_rank)
         if not dist.is_initialized():

@@ -153,3 +153,44 @@ def test_cli_reference_np_changes_order_only(tmp_path):
                 out.setdefault(name, []).append(rest)
         return sorted(map(tuple, out.values()))
     assert blocks(a) == blocks(b)
+
+
+# ----------------------------------------------------------------------------- two ranks (one GPU shared, gloo)
+
+def run_cli_world(args, out_dir, world=2):
+    """The CLI as `torch.distributed.run` starts it, `world` ranks sharing GPU 0 (gloo for the collectives:
+    RCCL wants one device per rank)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                   RANK=str(rank), LOCAL_RANK=str(rank), BSX_DIST_BACKEND='gloo')
+        cmd = [sys.executable, '-m', 'boolsi_amd'] + args + ['-o', out_dir, '--device', '0']
+        procs.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and not any('Exception caught' in o for o in outs), '\n'.join(outs)
+    return outs
+
+
+def test_two_ranks_write_the_same_files_as_one(tmp_path):
+    sim = next(c for c in load('listing.json') if c['mode'] == 'simulate' and c['np'] == 4)
+    tgt = next(c for c in load('listing.json') if c['mode'] == 'target' and c['np'] == 5)
+    (tmp_path / 'sim.yaml').write_text(sim['yaml'])
+    (tmp_path / 'tgt.yaml').write_text(tgt['yaml'])
+    (tmp_path / 'att.yaml').write_text(load('attract_toy.json')[0]['yaml'])
+    runs = [('sim', ['simulate', str(tmp_path / 'sim.yaml'), '-t', str(sim['max_t'])]),
+            ('simr', ['simulate', str(tmp_path / 'sim.yaml'), '-t', str(sim['max_t']), '--reference-np', '4', '-b', '5']),
+            ('tgt', ['target', str(tmp_path / 'tgt.yaml'), '-t', str(tgt['max_t'])]),
+            ('tgtn', ['target', str(tmp_path / 'tgt.yaml'), '-t', str(tgt['max_t']), '-n', '7']),
+            ('att', ['attract', str(tmp_path / 'att.yaml')])]
+    for name, args in runs:
+        run_cli(args, str(tmp_path / (name + '1')))
+        outs = run_cli_world(args, str(tmp_path / (name + '2')))
+        assert any('2 GPU' in o for o in outs), '\n'.join(outs)
+        files = sorted(f for f in os.listdir(tmp_path / (name + '1')) if f.endswith('.csv'))
+        assert files and files == sorted(f for f in os.listdir(tmp_path / (name + '2')) if f.endswith('.csv'))
+        for f in files:
+            assert read(tmp_path / (name + '1') / f) == read(tmp_path / (name + '2') / f), (name, f)
