@@ -26,6 +26,7 @@ hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStr
 hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
 hipError_t configure_attract(int nw, int k, bool lds, size_t shmem);
+hipError_t configure_attract_fast(int nw, int k, bool lds, size_t shmem, int* blocks_per_cu);
 hipError_t configure_target(int nw, int k, bool lds, size_t shmem);
 hipError_t configure_simulate(int nw, int k, bool lds, size_t shmem);
 }  // namespace bsx
@@ -75,6 +76,7 @@ struct bsx_engine {
 
     // cycle-state cache (valid for the current network + origin fixed nodes)
     bool cache_enabled = true;
+    int lean_blocks_per_cu = 0;  // occupancy of the lean attract kernel for the current network
     bool fast_ok = true;        // cleared when the lean kernel's straggler list overflowed for this space
     uint32_t cache_lds_slots = 0;
     DevBuf<CycleRecord> d_cc_journal;
@@ -293,14 +295,18 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     const size_t lut_bytes = lut.size() * 4;
     const size_t cache_stride = ((2 * nw + 2 + 3) & ~3u) * 4;
     uint32_t slots = 1;
-    while ((size_t)slots * 2 * cache_stride <= kCycleCacheLdsBytes) slots *= 2;
+    size_t cache_lds = kCycleCacheLdsBytes;
+    if (const char* kb = std::getenv("BSX_CACHE_LDS_KB")) cache_lds = std::max<size_t>(1, (size_t)std::atoi(kb)) * 1024;   // tuning knob
+    while ((size_t)slots * 2 * cache_stride <= cache_lds) slots *= 2;
     h->cache_lds_slots = slots;
     const size_t cache_bytes = (size_t)slots * cache_stride + 16 + 16      // + header + alignment
-                               + 128 * (8 + 4 + 4) + 8;                      // + lean kernel's LDS accumulators
+                               + kLeanAccBytes;                              // + lean kernel's LDS accumulators
     h->lut_in_lds = mask_bytes + lut_bytes + cache_bytes + 64 <= 144 * 1024;
     h->shmem = mask_bytes + (h->lut_in_lds ? lut_bytes : 0) + 64;
     h->shmem_attract = h->shmem + cache_bytes;
     HIPCHK(h, configure_attract((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract));
+    HIPCHK(h, configure_attract_fast((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract, &h->lean_blocks_per_cu));
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] network: nw %u k_mux %u lut_in_lds %d shmem %zu attract shmem %zu lean blocks/CU %d\n", nw, k_mux, (int)h->lut_in_lds, h->shmem, h->shmem_attract, h->lean_blocks_per_cu);
     HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
     HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
     h->have_net = true;
@@ -462,6 +468,7 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec
                         AttractRun& run) {
     const Launch L = plan_persistent(h, P.count, h->shmem_attract);
     P.chunk = L.chunk;
+    if (const char* c = std::getenv("BSX_CHUNK")) P.chunk = (uint32_t)std::max(64, std::atoi(c));     // tuning knob
     const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
     const uint64_t log_cap = waves * kTableSlots + (1u << 16);
     if (d_log.n < log_cap) HIPCHK(h, d_log.alloc(log_cap));
@@ -475,7 +482,7 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec
     HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
-    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu wave-iterations (%llu service rounds), lane utilisation %.3f, %.3f ms\n", fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec, (unsigned long long)run.ctr.wave_iters, (unsigned long long)run.ctr.service_rounds, run.ctr.wave_iters ? (double)run.ctr.steps_exec / (64.0 * (double)(run.ctr.wave_iters - run.ctr.service_rounds)) : 0.0, run.ms);
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu wave-iterations (%llu service rounds), chain walks %u, stragglers %llu, lane utilisation %.3f, %.3f ms, cycles/iter: head+service %.1f step %.1f; %llu waves, mean lifetime %.0f ticks = %.2f GHz if they live the whole kernel (prologue %.0f, epilogue %.0f)\n", fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec, (unsigned long long)run.ctr.wave_iters, (unsigned long long)run.ctr.service_rounds, run.ctr.pad, (unsigned long long)run.ctr.n_stragglers, run.ctr.wave_iters ? (double)run.ctr.steps_exec / (64.0 * (double)(run.ctr.wave_iters - run.ctr.service_rounds)) : 0.0, run.ms, run.ctr.wave_iters ? (double)run.ctr.cycles_service / (double)run.ctr.wave_iters : 0.0, run.ctr.wave_iters ? (double)run.ctr.cycles_step / (double)run.ctr.wave_iters : 0.0, (unsigned long long)run.ctr.n_waves, run.ctr.n_waves ? (double)run.ctr.cycles_wave / (double)run.ctr.n_waves : 0.0, run.ctr.n_waves ? (double)run.ctr.cycles_wave / (double)run.ctr.n_waves / (run.ms * 1e6) : 0.0, run.ctr.n_waves ? (double)run.ctr.cycles_prologue / (double)run.ctr.n_waves : 0.0, run.ctr.n_waves ? (double)run.ctr.cycles_epilogue / (double)run.ctr.n_waves : 0.0);
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
     if (!merged) return BSX_OK;
     const uint64_t n_log = run.ctr.log_cursor;

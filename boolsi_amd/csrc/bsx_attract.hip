@@ -1,4 +1,5 @@
-// attract kernels (general + lean) and their launchers
+// general attract kernel (detector + cycle-state cache) and its launchers; the lean kernel that takes
+// over once attractors are cached lives in bsx_lean.hip
 #include "bsx_kernels_common.h"
 
 namespace bsx {
@@ -11,47 +12,32 @@ namespace bsx {
 // is hit within kFastSteps the search restarts from s(T_p) in BRENT (detector + lookups) -> ADVANCE ->
 // MU -> DONE.  With a warm cache almost every lane ends in FAST, which carries no detector state.
 //
-// FAST_ONLY = true builds the lean kernel used once attractors are cached: only IDLE / FAST / DONE
-// exist, the cache mirror is static for the whole launch, the probe of the current state is issued
-// together with the gather reads of the next step, and a lane that hits nothing within
-// P.fast_steps hands its problem to the general kernel through the straggler list.
 // Minimum waves per SIMD requested from the register allocator (a 512-thread workgroup is 2 per SIMD).
-constexpr int attract_min_waves(int nw, bool fast) {
-    return fast ? (nw == 1 ? 8 : nw == 2 ? 6 : nw == 4 ? 4 : 2) : (nw <= 2 ? 4 : 2);
-}
+constexpr int attract_min_waves(int nw) { return nw <= 2 ? 4 : 2; }
 
-template <int NW, int K, bool LDS_LUT, bool FAST_ONLY>
-__global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_attract(const AttractParams P) {
+template <int NW, int K, bool LDS_LUT>
+__global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
     const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
-    const bool simple_space = FAST_ONLY || (P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv);
-    const bool use_cache = FAST_ONLY || P.cc.enabled != 0;
+    const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
+    const bool use_cache = P.cc.enabled != 0;
     const uint32_t fast_steps = P.fast_steps;
-    // lanes that must be waiting before a service round is worth its cost (measured: the lean kernel
-    // is fastest when most of the wave is served at once, profiles/r01_pmc.md)
-    const uint32_t service_lanes = P.pad ? P.pad : (FAST_ONLY ? 48u : kServiceLanes);
+    const uint32_t service_lanes = kServiceLanes;
     const uint32_t cmask = P.cc.lds_slots - 1;
 
     // LDS mirror of the cycle-state cache (pointer arithmetic on `smem` keeps the LDS address space:
     // a round trip through an integer would turn every probe into a flat load)
     uint32_t* lc = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);
-    // lean kernel: workgroup accumulators (LDS atomics) for cached attractors kTagAcc+1 .. kTagAcc+kLdsAcc
     const uint32_t lc_words = kCacheHeaderWords + P.cc.lds_slots * CacheLayout<NW>::kStride;
-    unsigned long long* acc_sl2 = reinterpret_cast<unsigned long long*>(lc + ((lc_words + 1u) & ~1u));
-    unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl2 + kLdsAcc);
-    unsigned int* acc_sl = acc_cnt + kLdsAcc;
     uint32_t cc_seen = 0, cc_states = 0, cc_attr = 0, cc_rounds = 0;       // meaningful in thread 0 only
     uint32_t fm0[NW], fv0[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; }
     if (use_cache) {
         for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
-        if constexpr (FAST_ONLY) {
-            for (uint32_t i = threadIdx.x; i < kLdsAcc; i += blockDim.x) { acc_sl2[i] = 0; acc_cnt[i] = 0; acc_sl[i] = 0; }
-        }
         __syncthreads();
         if (threadIdx.x == 0) cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
         __syncthreads();
@@ -84,20 +70,10 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     uint32_t ck[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) ck[w] = 0;
-    // Accumulators are 32-bit in the lean kernel: there T_p = 0 and mu <= fast_steps, and a lane sees
-    // at most count / (lanes in flight) problems, so the per-lane sums stay far below 2^32.
-    using acc_t = typename std::conditional<FAST_ONLY, uint32_t, uint64_t>::type;
-    constexpr acc_t kSqGuard = FAST_ONLY ? (acc_t)0x7FFF0000u : (acc_t)(1ull << 62);
+    using acc_t = uint64_t;
+    constexpr acc_t kSqGuard = (acc_t)(1ull << 62);
     uint32_t clen = 0, ccnt = 0;
     acc_t csl = 0, csl2 = 0;
-
-    // Lean kernel: results of the first kTagAcc cached attractors are summed per lane by tag with
-    // predicated adds (no key compare, no cross-lane merge until the kernel ends); consecutive problems
-    // alternate between a few attractors, and flushing the one-entry run cache on every change was the
-    // dominant cost of a service round.
-    uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
-#pragma unroll
-    for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
 
     acc_t steps_ref = 0, steps_exec = 0;       // steps_ref: found problems only; the others add max_t each
     uint32_t n_none = 0, n_capfail = 0, limit_hits = 0;
@@ -106,21 +82,9 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     unsigned long long dbg_iters = 0, dbg_service = 0;
 #endif
     WaveQueue q{0, 0, true};
-    if constexpr (FAST_ONLY) vis = cache_visible(lc);      // static for the launch: nobody inserts
 
     // start of the search at s(T_p) = A: snapshot the cache, look s(T_p) itself up, pick the mode
     auto begin_search = [&]() {
-        if constexpr (FAST_ONLY) {          // probe s(T_p) itself, then step + probe per iteration
-            uint32_t l0 = 0, k0[NW], tag0 = 0;
-            t = 0;
-            if (cache_lookup<NW>(lc, cmask, vis, A, l0, k0, &tag0)) {
-                phase = PH_DONE; lam = l0; pub = tag0; cnt = 0; sub = (l0 <= cap_rel) ? 1u : 0u;     // mu = 0
-                copy_words<NW>(D, k0);
-            } else {
-                phase = PH_FAST;
-            }
-            return;
-        }
         copy_words<NW>(D, A);
         t = 0; pub = 0;
         vis = use_cache ? cache_visible(lc) : 0u;
@@ -178,24 +142,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                     P.per_problem[my_p] = r;
                 }
                 const acc_t sq = (acc_t)traj32 * traj32;
-                bool by_tag = false;
-                if constexpr (FAST_ONLY) {
-                    by_tag = keep && pub <= (uint32_t)kTagAcc;
-#pragma unroll
-                    for (int j = 0; j < kTagAcc; ++j) {
-                        const bool m = by_tag && pub == (uint32_t)(j + 1);
-                        tcnt[j] += m ? 1u : 0u;
-                        tsl[j] += m ? traj32 : 0u;
-                        tsl2[j] += m ? (uint32_t)sq : 0u;
-                    }
-                }
                 if (!keep) ++n_none;
-                else if (by_tag) {}
-                else if constexpr (FAST_ONLY) {         // attractors beyond the register accumulators
-                    atomicAdd(&acc_cnt[pub - 1 - kTagAcc], 1u);
-                    atomicAdd(&acc_sl[pub - 1 - kTagAcc], traj32);
-                    atomicAdd(&acc_sl2[pub - 1 - kTagAcc], (unsigned long long)sq);
-                }
                 else if (ccnt && eq_words<NW>(ck, D) && csl2 < kSqGuard) { ++ccnt; csl += traj_l; csl2 += sq; }
                 else {
                     if (ccnt) { flush = true; copy_words<NW>(fk, ck); flen = clen; fcnt = ccnt; fsl = csl; fsl2 = csl2; }
@@ -206,7 +153,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
 
             // ---- cycle-state cache upkeep (rare): pull what others published; one lane per newly
             //      detected attractor appends it to the journal
-            if (!FAST_ONLY && use_cache) {
+            if (use_cache) {
                 if (threadIdx.x == 0 && (++cc_rounds & 31u) == 0)
                     cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, cc_seen, cc_states, cc_attr);
                 uint64_t cand = __ballot(want_pub);
@@ -233,11 +180,11 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (phase == PH_IDLE && rank < avail) {
                         my_p = q.next + rank;
-                        if (!FAST_ONLY && P.offsets) my_p = P.offsets[my_p];
+                        if (P.offsets) my_p = P.offsets[my_p];
                         exec32 = 0;
                         if (simple_space) {
                             init_problem_simple<NW>(P.sp, my_p, A);
-                        } else if constexpr (!FAST_ONLY) {
+                        } else {
                             Problem<NW> pr;
                             init_problem<NW>(P.sp, my_p, pr);
                             copy_words<NW>(A, pr.s); copy_words<NW>(fm, pr.fm); copy_words<NW>(fv, pr.fv);
@@ -253,44 +200,6 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
                 }
             }
             continue;       // re-evaluate the wave state (nothing to step if every lane is idle)
-        }
-
-        if constexpr (FAST_ONLY) {
-            // ---- lean iteration: s(T_p + t + 1), then its probe (s(T_p) itself was probed at refill)
-            uint32_t nxt[NW], l2 = 0, k2[NW];
-#pragma unroll
-            for (int w = 0; w < NW; ++w) k2[w] = 0;
-            uint32_t tag = 0;
-            net_step<NW, K>(nv, A, fm0, fv0, nxt);
-            if (has_warmup && phase == PH_WARM) {       // uniform origin schedule only (no variations here)
-                ++t; ++exec32;
-                apply_perturbations<NW>(P.sp, t, 0ull, nxt);
-                copy_words<NW>(A, nxt);
-                if (t == tp) begin_search();
-                continue;
-            }
-            const bool hit = cache_lookup<NW>(lc, cmask, vis, nxt, l2, k2, &tag);
-            if (phase == PH_FAST) {
-                ++exec32;
-                const uint32_t t1 = t + 1;
-                const bool ok = hit && t1 <= cap_rel && l2 <= cap_rel - t1;     // mu + lambda <= max_t - T_p
-                const bool lost = !hit && t1 >= fast_steps;
-                if (lost) {
-                    const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
-                    if (at < P.stragglers_cap) P.stragglers[at] = (uint32_t)my_p;
-                    else atomicOr(&P.ctr->straggler_overflow, 1u);
-                    steps_exec += exec32;
-                }
-#pragma unroll
-                for (int w = 0; w < NW; ++w) { D[w] = hit ? k2[w] : D[w]; A[w] = nxt[w]; }
-                lam = l2;
-                pub = tag;
-                cnt = ok ? t1 : 0u;
-                sub = ok ? 1u : 0u;
-                t = t1;
-                phase = hit ? PH_DONE : (lost ? PH_IDLE : PH_FAST);
-            }
-            continue;
         }
 
         // ---- one network update per lane per iteration
@@ -382,85 +291,33 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW, FAST_ONLY)) void k_at
     }
 
     // ---- epilogue: lane caches -> wave table -> HBM log; counters
-    if constexpr (FAST_ONLY) {
-        // per-tag sums -> wave table: key and length of tag j + 1 from any of its mirror entries
-        constexpr int S = CacheLayout<NW>::kStride;
-        const uint32_t* base = lc + kCacheHeaderWords;
-#pragma unroll
-        for (int j = 0; j < kTagAcc; ++j) {
-            if (!__ballot(tcnt[j] != 0)) continue;
-            uint32_t k[NW], len = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) k[w] = 0;
-            for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
-                if (base[sl * S + NW] == (uint32_t)(j + 1)) {
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) k[w] = base[sl * S + NW + 2 + w];
-                    len = base[sl * S + NW + 1];
-                    break;
-                }
-            }
-            table_merge<NW>(P, slot, lane, tcnt[j] != 0, k, len, tcnt[j], (uint64_t)tsl[j], (uint64_t)tsl2[j]);
-        }
-        // workgroup accumulators -> HBM log, one thread per attractor
-        __syncthreads();
-        for (uint32_t a = threadIdx.x; a < kLdsAcc; a += blockDim.x) {
-            const uint32_t cn = acc_cnt[a];
-            if (!cn) continue;
-            for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
-                if (base[sl * S + NW] == a + 1 + kTagAcc) {
-                    uint32_t k[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) k[w] = base[sl * S + NW + 2 + w];
-                    log_append<NW>(P, k, base[sl * S + NW + 1], cn, (uint64_t)acc_sl[a], (uint64_t)acc_sl2[a]);
-                    break;
-                }
-            }
-        }
-    }
     table_merge<NW>(P, slot, lane, ccnt != 0, ck, clen, ccnt, csl, csl2);
     if (slot.count) log_append<NW>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
 #ifdef BSX_DIAG
     if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_service); }
 #endif
-    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_ref +
-                                     (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t));
-    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps_exec);
-    if (n_none) atomicAdd(&P.ctr->n_none, (unsigned long long)n_none);
-    if (limit_hits) atomicAdd(&P.ctr->step_limit_hits, limit_hits);
+    wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps_ref +
+                                           (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), lane);
+    wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps_exec, lane);
+    wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, lane);
+    wave_atomic_add(&P.ctr->step_limit_hits, limit_hits, lane);
 }
 
 template <int NW, int K>
 static hipError_t launch_attract_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true, false>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_attract<NW, K, false, false>), grid, dim3(kBlock), shmem, st, P);
-    return hipGetLastError();
-}
-template <int NW, int K>
-static hipError_t launch_attract_fast_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true, true>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_attract<NW, K, false, true>), grid, dim3(kBlock), shmem, st, P);
+    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
+    else hipLaunchKernelGGL((k_attract<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
     return hipGetLastError();
 }
 template <int NW, int K>
 static hipError_t configure_attract_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
     const int bytes = (int)shmem;
-    hipError_t e;
-    if (lds) {
-        e = hipFuncSetAttribute((const void*)k_attract<NW, K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_attract<NW, K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    } else {
-        e = hipFuncSetAttribute((const void*)k_attract<NW, K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_attract<NW, K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    }
-    return e;
+    if (lds) return hipFuncSetAttribute((const void*)k_attract<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute((const void*)k_attract<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
     BSX_DISPATCH(launch_attract_nk)
-}
-hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    BSX_DISPATCH(launch_attract_fast_nk)
 }
 // Allow the instantiation used by a network to take `shmem` bytes of dynamic LDS (above 64 KiB this
 // must be requested explicitly).

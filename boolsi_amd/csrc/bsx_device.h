@@ -80,6 +80,12 @@ struct Counters {               // zeroed before every launch
     unsigned int pad;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic
+    unsigned long long cycles_service;  // diagnostic (BSX_DIAG): shader cycles summed over waves
+    unsigned long long cycles_step;
+    unsigned long long cycles_wave;     // diagnostic: wave lifetimes
+    unsigned long long n_waves;
+    unsigned long long cycles_prologue;
+    unsigned long long cycles_epilogue;
 };
 
 // Cache of known cycle states (DESIGN.md "cycle-state cache").  A trajectory enters its attractor at
@@ -93,6 +99,11 @@ constexpr uint32_t kCycleCacheMaxLen = 64;        // longer cycles are not cache
 constexpr uint32_t kCycleCacheLdsBytes = 16 * 1024;
 constexpr uint32_t kCycleJournalCap = 4096;       // attractors
 constexpr uint32_t kCycleClaimSlots = 8192;       // fingerprints of published keys (dedupe)
+// Lean attract kernel: results of cached attractors 1..kTagAcc are summed in registers per lane; all
+// of 1..kTagAcc+kLdsAcc have per-workgroup LDS accumulators (sum l^2 u64, sum l u64, count u32).
+constexpr int kTagAcc = 3;
+constexpr uint32_t kLdsAcc = 128;
+constexpr uint32_t kLeanAccBytes = (kTagAcc + kLdsAcc) * (8 + 8 + 4) + 16;
 
 struct CycleRecord {
     uint32_t key[kMaxW32];

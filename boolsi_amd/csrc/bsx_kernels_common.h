@@ -96,6 +96,21 @@ struct NetView {
     const uint32_t* wide_tt;
 };
 
+// ((v >> 8*B) & 0xFF) * scale in one instruction (SDWA byte select on the second operand; the scale
+// lives in a VGPR because SDWA takes no literal).
+__device__ __forceinline__ uint32_t byte_times(uint32_t v, uint32_t scale, int B) {   // B: constant after unrolling
+    uint32_t r;
+    if (B == 0)
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(scale), "v"(v));
+    else if (B == 1)
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(scale), "v"(v));
+    else if (B == 2)
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(scale), "v"(v));
+    else
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(scale), "v"(v));
+    return r;
+}
+
 // Load one LUT entry (N consecutive words) with the widest loads its size allows.
 template <int N>
 __device__ __forceinline__ void load_entry(const uint32_t* e, uint32_t (&dst)[N]) {
@@ -143,8 +158,11 @@ __device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_
         for (int b = 0; b < kBatch; ++b) {
             const int ch = c0 + b;
             if (ch < NW * 4) {
-                const uint32_t v = (s[ch >> 2] >> ((ch & 3) * 8)) & 0xFFu;
-                load_entry<kEntry>(nv.lut + ((uint32_t)(ch << 8) + v) * kEntry, e[b]);
+                // byte offset of the entry within its chunk's table: (byte ch of the state) * entry size,
+                // one SDWA multiply instead of extract + scale
+                const uint32_t off = byte_times(s[ch >> 2], (uint32_t)(kEntry * 4), ch & 3);
+                load_entry<kEntry>(reinterpret_cast<const uint32_t*>(
+                                       reinterpret_cast<const char*>(nv.lut + (uint32_t)(ch << 8) * kEntry) + off), e[b]);
             }
         }
 #pragma unroll
@@ -343,6 +361,27 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Counter totals leave a wave as ONE atomic: 64 lanes adding to the same address are 64 serialised
+// operations at the L2 atomic unit, and with every wave of the grid doing that at the end of a launch
+// the queue behind one address was 20 % of the lean attract kernel's run time.
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ __forceinline__ void wave_atomic_add(unsigned long long* dst, unsigned long long v, int lane) {
+    const unsigned long long total = wave_sum(v);
+    if (lane == 0 && total) atomicAdd(dst, total);
+}
+__device__ __forceinline__ void wave_atomic_add(unsigned int* dst, unsigned int v, int lane) {
+    const unsigned long long total = wave_sum((unsigned long long)v);
+    if (lane == 0 && total) atomicAdd(dst, (unsigned int)total);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-wave attractor table: slot i lives in lane i's registers, so a probe is one compare per lane
 // and two ballots (attract.py:374-402 store_attractor, integer sums instead of Chan's float update).
@@ -448,17 +487,19 @@ __device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]) {
 
 // LDS mirror: word 0 of the header = number of attractors whose states are all inserted ("visible");
 // an entry's tag is the 1-based sequence number of its attractor and counts only when <= visible.
+// Bit 31 of the tag word is the "continue" flag: some later insert had to skip over this (occupied)
+// slot, so a lookup that lands here on a different state must look at the next slot too.  Without the
+// flag every lookup landing on an occupied slot would have to walk on, and with 64 lanes probing
+// mostly non-cycle states that was the case in four wave iterations out of five.
 constexpr int kCacheHeaderWords = 4;
-// Lean attract kernel: results of cached attractors 1..kTagAcc are summed in registers per lane,
-// kTagAcc+1 .. kTagAcc+kLdsAcc in per-workgroup LDS accumulators; later ones are left to the detector.
-constexpr int kTagAcc = 3;
-constexpr uint32_t kLdsAcc = 128;
+constexpr uint32_t kTagCont = 0x80000000u;
+constexpr uint32_t kTagMask = 0x7FFFFFFFu;
 
 // One probe: loads the whole entry with no control flow in between (so the reads are issued together
 // with whatever else the caller has in flight) and classifies it.
 template <int NW>
 struct CacheProbe {
-    uint32_t tag, length;
+    uint32_t tagw, length;      // tag word (tag | continue flag)
     uint32_t key[NW];
     bool same;                  // entry holds exactly this state
 };
@@ -470,24 +511,23 @@ __device__ __forceinline__ CacheProbe<NW> cache_probe(const uint32_t* base, uint
     CacheProbe<NW> p;
     if constexpr (NW == 1) {
         const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-        p.tag = v.y; p.length = v.z; p.key[0] = v.w; p.same = v.x == s[0];
+        p.tagw = v.y; p.length = v.z; p.key[0] = v.w; p.same = v.x == s[0];
     } else if constexpr (NW == 2) {
         const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
         const uint2 k = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(e + 4, 8));
-        p.tag = v.z; p.length = v.w; p.key[0] = k.x; p.key[1] = k.y;
-        p.same = v.x == s[0] && v.y == s[1];
+        p.tagw = v.z; p.length = v.w; p.key[0] = k.x; p.key[1] = k.y;
+        p.same = ((v.x ^ s[0]) | (v.y ^ s[1])) == 0;
     } else {
         uint32_t d = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { d |= e[w] ^ s[w]; p.key[w] = e[NW + 2 + w]; }
-        p.tag = e[NW]; p.length = e[NW + 1]; p.same = d == 0;
+        p.tagw = e[NW]; p.length = e[NW + 1]; p.same = d == 0;
     }
     return p;
 }
 
 // Is `s` a state of an attractor with sequence number <= visible?  The first probe is branch-free;
-// only lanes that land on another attractor's (or a not yet visible) entry keep walking the chain
-// (the table is at most half full, so a walk ends at an empty tag).
+// only lanes that land on a different state in a slot flagged "continue" keep walking the chain.
 template <int NW>
 __device__ __forceinline__ bool cache_lookup(const uint32_t* lc, uint32_t mask, uint32_t visible,
                                              const uint32_t (&s)[NW], uint32_t& length, uint32_t (&key)[NW],
@@ -495,21 +535,21 @@ __device__ __forceinline__ bool cache_lookup(const uint32_t* lc, uint32_t mask, 
     const uint32_t* base = lc + kCacheHeaderWords;
     uint32_t h = hash_state<NW>(s) & mask;
     CacheProbe<NW> p = cache_probe<NW>(base, h, s);
-    bool hit = p.tag != 0 && p.tag <= visible && p.same;
-    bool walking = p.tag != 0 && !hit;
+    bool hit = ((p.tagw & kTagMask) - 1u < visible) & p.same;
+    bool walking = (p.tagw >> 31) != 0 && !hit;
     if (__builtin_expect(__ballot(walking) != 0, 0)) {
         while (walking) {
             h = (h + 1) & mask;
             const CacheProbe<NW> q = cache_probe<NW>(base, h, s);
-            const bool here = q.tag != 0 && q.tag <= visible && q.same;
+            const bool here = ((q.tagw & kTagMask) - 1u < visible) & q.same;
             if (here) { p = q; hit = true; }
-            walking = q.tag != 0 && !here;
+            walking = (q.tagw >> 31) != 0 && !here;
         }
     }
     length = p.length;
 #pragma unroll
     for (int w = 0; w < NW; ++w) key[w] = p.key[w];
-    if (tag_out) *tag_out = p.tag;
+    if (tag_out) *tag_out = p.tagw & kTagMask;
     return hit;
 }
 
@@ -517,14 +557,19 @@ __device__ __forceinline__ uint32_t cache_visible(const uint32_t* lc) {
     return __hip_atomic_load(lc, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Single-thread insert into the LDS mirror (only thread 0 of a workgroup writes it).
+// Single-thread insert into the LDS mirror (only thread 0 of a workgroup writes it).  Occupied slots
+// on the way get their "continue" flag set; readers that raced past them before that miss a state of
+// an attractor that is not visible to them yet anyway.
 template <int NW>
 __device__ __forceinline__ void cache_insert_lds(uint32_t* lc, uint32_t mask, const uint32_t (&s)[NW],
                                                  uint32_t length, const uint32_t (&key)[NW], uint32_t tag) {
     constexpr int S = CacheLayout<NW>::kStride;
     uint32_t* base = lc + kCacheHeaderWords;
     uint32_t h = hash_state<NW>(s) & mask;
-    while (base[h * S + NW] != 0) h = (h + 1) & mask;
+    while (base[h * S + NW] != 0) {
+        base[h * S + NW] |= kTagCont;
+        h = (h + 1) & mask;
+    }
     uint32_t* e = base + h * S;
 #pragma unroll
     for (int w = 0; w < NW; ++w) { e[w] = s[w]; e[NW + 2 + w] = key[w]; }

@@ -48,8 +48,8 @@ __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
         }
         if (P.digests) P.digests[qi] = dg;
     }
-    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps);
-    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps);
+    wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps, (int)(threadIdx.x & 63));
+    wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps, (int)(threadIdx.x & 63));
 }
 
 

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
             if (t == tp) { phase = PH_BRENT; lam = 0; power = 1; copy_words<NW>(B, A); }
         }
     }
-    atomicAdd(&P.ctr->steps_ref, (unsigned long long)steps_exec);
-    atomicAdd(&P.ctr->steps_exec, (unsigned long long)steps_exec);
-    if (n_hits) atomicAdd(&P.ctr->log_cursor, (unsigned long long)n_hits);
-    if (limit_hits) atomicAdd(&P.ctr->step_limit_hits, limit_hits);
+    wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps_exec, lane);
+    wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps_exec, lane);
+    wave_atomic_add(&P.ctr->log_cursor, (unsigned long long)n_hits, lane);
+    wave_atomic_add(&P.ctr->step_limit_hits, limit_hits, lane);
 }
 
 // Ordered stream compaction of t_hit[] into the hit list: pass 1 counts hits per segment, the host
