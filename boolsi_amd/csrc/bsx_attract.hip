@@ -19,7 +19,7 @@ template <int NW, int K, bool LDS_LUT>
 __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
     const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;

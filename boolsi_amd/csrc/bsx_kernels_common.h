@@ -84,9 +84,13 @@ __device__ __forceinline__ void put_bit(uint32_t (&s)[NW], uint32_t node, uint32
 
 // ------------------------------------------------------------------------------------------------
 // Network tables as seen by a workgroup: LUT and masks either in LDS or (large networks) in HBM/L2.
-template <int NW, int K>
+template <int NW, int K, bool LDS = false>
 struct NetView {
     static constexpr bool kMasksInRegs = (K <= 3);
+    // LDS = true: the gather LUT sits in LDS right behind the masks, and the kernel's dynamic LDS starts
+    // at LDS address 0 (checked by stage_network), so an entry's address is a compile-time constant plus
+    // the scaled byte -- no base-pointer add per lookup.
+    static constexpr uint32_t kLutLdsByte = ((((1u << K) * NW) + 3u) & ~3u) * 4u;
     const uint32_t* lut;     // LDS or global
     const uint32_t* masks;   // LDS (used when the 2^K * NW mask words do not fit the register budget)
     uint32_t mreg[kMasksInRegs ? (1 << K) * NW : 1];
@@ -134,9 +138,38 @@ __device__ __forceinline__ void load_entry(const uint32_t* e, uint32_t (&dst)[N]
     }
 }
 
+// Same from an LDS byte address (address space 3 pointer made from the integer).
+typedef uint32_t bsx_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t bsx_u32x4 __attribute__((ext_vector_type(4)));
+template <int N>
+__device__ __forceinline__ void load_entry_lds(uint32_t byte_addr, uint32_t (&dst)[N]) {
+    typedef const uint32_t __attribute__((address_space(3))) lds_u32;
+    typedef const bsx_u32x2 __attribute__((address_space(3))) lds_u32x2;
+    typedef const bsx_u32x4 __attribute__((address_space(3))) lds_u32x4;
+    if constexpr (N % 4 == 0) {
+        lds_u32x4* p = reinterpret_cast<lds_u32x4*>(byte_addr);
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const bsx_u32x4 v = p[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else if constexpr (N % 2 == 0) {
+        lds_u32x2* p = reinterpret_cast<lds_u32x2*>(byte_addr);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const bsx_u32x2 v = p[i];
+            dst[2 * i] = v.x; dst[2 * i + 1] = v.y;
+        }
+    } else {
+        lds_u32* p = reinterpret_cast<lds_u32*>(byte_addr);
+#pragma unroll
+        for (int i = 0; i < N; ++i) dst[i] = p[i];
+    }
+}
+
 // One synchronous update of all nodes (model.py:16-28) + fixed nodes as constants (model.py:31-49).
-template <int NW, int K>
-__device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_t (&s)[NW],
+template <int NW, int K, bool LDS>
+__device__ __forceinline__ void net_step(const NetView<NW, K, LDS>& nv, const uint32_t (&s)[NW],
                                          const uint32_t (&fm)[NW], const uint32_t (&fv)[NW],
                                          uint32_t (&out)[NW]) {
     uint32_t g[K][NW];
@@ -161,8 +194,11 @@ __device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_
                 // byte offset of the entry within its chunk's table: (byte ch of the state) * entry size,
                 // one SDWA multiply instead of extract + scale
                 const uint32_t off = byte_times(s[ch >> 2], (uint32_t)(kEntry * 4), ch & 3);
-                load_entry<kEntry>(reinterpret_cast<const uint32_t*>(
-                                       reinterpret_cast<const char*>(nv.lut + (uint32_t)(ch << 8) * kEntry) + off), e[b]);
+                if constexpr (LDS)
+                    load_entry_lds<kEntry>(NetView<NW, K, LDS>::kLutLdsByte + (uint32_t)(ch << 8) * kEntry * 4u + off, e[b]);
+                else
+                    load_entry<kEntry>(reinterpret_cast<const uint32_t*>(
+                                           reinterpret_cast<const char*>(nv.lut + (uint32_t)(ch << 8) * kEntry) + off), e[b]);
             }
         }
 #pragma unroll
@@ -181,7 +217,7 @@ __device__ __forceinline__ void net_step(const NetView<NW, K>& nv, const uint32_
     for (int i = 0; i < (1 << (K - 1)); ++i)
 #pragma unroll
         for (int w = 0; w < NW; ++w)
-            r[i][w] = NetView<NW, K>::kMasksInRegs
+            r[i][w] = NetView<NW, K, LDS>::kMasksInRegs
                           ? bfi(g[0][w], nv.mreg[(2 * i + 1) * NW + w], nv.mreg[(2 * i) * NW + w])
                           : bfi(g[0][w], nv.masks[(2 * i + 1) * NW + w], nv.masks[(2 * i) * NW + w]);
 #pragma unroll
@@ -321,8 +357,13 @@ __device__ __forceinline__ void apply_perturbations(const DevSpace& sp, uint32_t
 // ------------------------------------------------------------------------------------------------
 // Workgroup prologue: stage LUT + masks into LDS.
 template <int NW, int K, bool LDS_LUT>
-__device__ __forceinline__ NetView<NW, K> stage_network(const DevNet& net, uint32_t* smem, uint32_t*& smem_free) {
-    NetView<NW, K> nv;
+__device__ __forceinline__ NetView<NW, K, LDS_LUT> stage_network(const DevNet& net, uint32_t* smem, uint32_t*& smem_free) {
+    NetView<NW, K, LDS_LUT> nv;
+    if constexpr (LDS_LUT) {
+        // net_step addresses the LUT by absolute LDS byte offsets: the dynamic LDS block must start at 0
+        // (true for kernels without static LDS; anything else is a build error, so stop loudly)
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)smem != 0u) __builtin_trap();
+    }
     uint32_t* p = smem;
     uint32_t* smasks = p;
     const uint32_t n_masks = (1u << K) * NW;
@@ -341,7 +382,7 @@ __device__ __forceinline__ NetView<NW, K> stage_network(const DevNet& net, uint3
     }
     __syncthreads();
     nv.masks = smasks;
-    if constexpr (NetView<NW, K>::kMasksInRegs) {
+    if constexpr (NetView<NW, K, LDS_LUT>::kMasksInRegs) {
 #pragma unroll
         for (int i = 0; i < (1 << K) * NW; ++i) nv.mreg[i] = smasks[i];
     } else {
@@ -579,8 +620,8 @@ __device__ __forceinline__ void cache_insert_lds(uint32_t* lc, uint32_t mask, co
 
 // Thread 0: take the attractors published since `seen` (by any workgroup) from the HBM journal,
 // regenerate their cycles from the key and make each cycle visible in the LDS mirror at once.
-template <int NW, int K>
-__device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<NW, K>& nv,
+template <int NW, int K, bool LDS>
+__device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<NW, K, LDS>& nv,
                                            const uint32_t (&fm)[NW], const uint32_t (&fv)[NW], uint32_t* lc,
                                            uint32_t& seen, uint32_t& n_states, uint32_t& n_attr) {
     const uint32_t mask = cc.lds_slots - 1;

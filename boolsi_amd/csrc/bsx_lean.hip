@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     const unsigned long long c_begin = __builtin_readcyclecounter();
 #endif
     uint32_t* smem_free;
-    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
     const bool has_warmup = tp != 0;

@@ -9,7 +9,7 @@ template <int NW, int K, bool LDS_LUT>
 __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t steps = 0;
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < P.count; qi += stride) {

@@ -21,7 +21,7 @@ template <int NW, int K, bool LDS_LUT>
 __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const TargetParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
 
