@@ -300,7 +300,7 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     while ((size_t)slots * 2 * cache_stride <= cache_lds) slots *= 2;
     h->cache_lds_slots = slots;
     const size_t cache_bytes = (size_t)slots * cache_stride + 16 + 16      // + header + alignment
-                               + kLeanAccBytes;                              // + lean kernel's LDS accumulators
+                               + lean_acc_bytes(nw);                         // + lean kernel's per-attractor tables
     h->lut_in_lds = mask_bytes + lut_bytes + cache_bytes + 64 <= 144 * 1024;
     h->shmem = mask_bytes + (h->lut_in_lds ? lut_bytes : 0) + 64;
     h->shmem_attract = h->shmem + cache_bytes;

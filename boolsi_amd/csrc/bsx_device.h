@@ -100,10 +100,12 @@ constexpr uint32_t kCycleCacheLdsBytes = 16 * 1024;
 constexpr uint32_t kCycleJournalCap = 4096;       // attractors
 constexpr uint32_t kCycleClaimSlots = 8192;       // fingerprints of published keys (dedupe)
 // Lean attract kernel: results of cached attractors 1..kTagAcc are summed in registers per lane; all
-// of 1..kTagAcc+kLdsAcc have per-workgroup LDS accumulators (sum l^2 u64, sum l u64, count u32).
+// of 1..kTagAcc+kLdsAcc have per-workgroup LDS accumulators (sum l^2 u64, sum l u64, count u32) next
+// to their length and key (for the log records / per-problem records).  Later attractors are left to
+// the general kernel.
 constexpr int kTagAcc = 3;
-constexpr uint32_t kLdsAcc = 128;
-constexpr uint32_t kLeanAccBytes = (kTagAcc + kLdsAcc) * (8 + 8 + 4) + 16;
+constexpr uint32_t kLdsAcc = 61;
+constexpr uint32_t lean_acc_bytes(uint32_t nw) { return (kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4 + 4 * nw) + 16; }
 
 struct CycleRecord {
     uint32_t key[kMaxW32];

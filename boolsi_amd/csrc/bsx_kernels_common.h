@@ -623,7 +623,8 @@ __device__ __forceinline__ void cache_insert_lds(uint32_t* lc, uint32_t mask, co
 template <int NW, int K, bool LDS>
 __device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<NW, K, LDS>& nv,
                                            const uint32_t (&fm)[NW], const uint32_t (&fv)[NW], uint32_t* lc,
-                                           uint32_t& seen, uint32_t& n_states, uint32_t& n_attr) {
+                                           uint32_t& seen, uint32_t& n_states, uint32_t& n_attr,
+                                           uint32_t max_attr = 0xFFFFFFFFu) {
     const uint32_t mask = cc.lds_slots - 1;
     uint32_t jc = __hip_atomic_load(cc.journal_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (jc > kCycleJournalCap) jc = kCycleJournalCap;
@@ -637,7 +638,7 @@ __device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<N
         ++seen;
         uint32_t l2, k2[NW];
         if (cache_lookup<NW>(lc, mask, n_attr, key, l2, k2)) continue;              // duplicate record
-        if (len == 0 || len > kCycleCacheMaxLen || n_states + len > cc.lds_slots / 2) continue;   // does not fit
+        if (len == 0 || len > kCycleCacheMaxLen || n_states + len > cc.lds_slots / 2 || n_attr >= max_attr) continue;   // does not fit
         const uint32_t tag = n_attr + 1;
         copy_words<NW>(s, key);
         for (uint32_t i = 0; i < len; ++i) {

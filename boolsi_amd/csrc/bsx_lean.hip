@@ -18,7 +18,8 @@ namespace bsx {
 // read-only for the whole launch, and a result is just (attractor tag, mu):
 //   * results of cached attractors 1..kTagAcc are summed per lane in registers by predicated adds,
 //     later ones (and register sums about to overflow) by LDS atomics into per-workgroup accumulators;
-//     nothing crosses lanes before the kernel ends;
+//     nothing crosses lanes before the kernel ends, when every workgroup writes one log record per
+//     attractor; the step counters follow from those sums;
 //   * t runs from -T_p: time <= 0 is the warm-up (perturbations applied, hits ignored), so warm-up and
 //     search are the same loop body;
 //   * resolved lanes wait for a service round (record + refill), entered when P.pad lanes (default
@@ -26,49 +27,60 @@ namespace bsx {
 constexpr uint32_t kLeanServiceLanes = 32;
 constexpr uint32_t kRegSumGuard = 0x7FFF0000u;      // per-lane 32-bit sums of trajectory_l^2 stay below 2^32
 
-// (LUT + cache mirror take ~50 KiB of LDS per workgroup for n = 64: 3 workgroups = 6 waves per SIMD)
+// (LUT + cache mirror take ~52 KiB of LDS per workgroup for n = 64: 3 workgroups = 6 waves per SIMD)
 constexpr int lean_min_waves(int nw) { return nw <= 2 ? 6 : nw == 4 ? 4 : 2; }
 
-enum LeanState : uint32_t { LS_IDLE = 0, LS_RUN = 1, LS_HIT = 2, LS_LOST = 3 };
+// Lane status word: 0 = running; a hit leaves the entry's tag word (attractor number, maybe with the
+// continue flag); the two codes below have bit 31 clear and are no attractor numbers.
+constexpr uint32_t kResLost = 0x7FFFFFFEu;
+constexpr uint32_t kResIdle = 0x7FFFFFFFu;
 
 template <int NW, int K, bool LDS_LUT>
 __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-#ifdef BSX_DIAG
-    const unsigned long long c_begin = __builtin_readcyclecounter();
-#endif
     uint32_t* smem_free;
     const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
     const bool has_warmup = tp != 0;
-    const uint32_t fast_steps = P.fast_steps;
+    const int32_t fast_steps = (int32_t)P.fast_steps;
     const uint32_t service_lanes = P.pad ? P.pad : kLeanServiceLanes;
     const uint32_t cmask = P.cc.lds_slots - 1;
     constexpr int S = CacheLayout<NW>::kStride;
-    constexpr uint32_t kAccs = (uint32_t)kTagAcc + kLdsAcc;          // attractors the accumulators cover
+    constexpr uint32_t kAccs = (uint32_t)kTagAcc + kLdsAcc;          // attractors this kernel resolves
 
-    // LDS: [network tables][cache mirror][accumulators: sum l^2 (u64), sum l (u64), count (u32)]
+    // LDS: [network tables][cache mirror][per attractor: sum l^2, sum l (u64), count, length (u32), key]
     uint32_t* lc = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);
     const uint32_t lc_words = kCacheHeaderWords + P.cc.lds_slots * S;
     unsigned long long* acc_sl2 = reinterpret_cast<unsigned long long*>(lc + ((lc_words + 1u) & ~1u));
     unsigned long long* acc_sl = acc_sl2 + kAccs;
     unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl + kAccs);
+    uint32_t* lamtab = acc_cnt + kAccs;
+    uint32_t* keytab = lamtab + kAccs;
 
     uint32_t fm0[NW], fv0[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; }
     for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
-    for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // only the first kAccs attractors of the journal enter the mirror, so every occupied slot is a
+        // hit candidate and the probe needs no visibility compare; the rest become stragglers
         uint32_t seen = 0, n_states = 0, n_attr = 0;
-        cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, seen, n_states, n_attr);
+        cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, seen, n_states, n_attr, kAccs);
     }
     __syncthreads();
-    // attractors beyond the accumulators stay invisible: their problems become stragglers
-    uint32_t vis = cache_visible(lc);
-    vis = vis < kAccs ? vis : kAccs;
+    const uint32_t* cbase = lc + kCacheHeaderWords;
+    for (uint32_t sl = threadIdx.x; sl < P.cc.lds_slots; sl += blockDim.x) {
+        const uint32_t tg = cbase[sl * S + NW] & kTagMask;
+        if (tg) {       // every entry of an attractor writes the same values
+            lamtab[tg - 1] = cbase[sl * S + NW + 1];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) keytab[(tg - 1) * NW + w] = cbase[sl * S + NW + 2 + w];
+        }
+    }
+    __syncthreads();
 
     // found iff mu + lambda <= max_t - T_p (S7)
     const uint32_t cap_rel = (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)(P.max_t - tp);
@@ -76,132 +88,118 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     uint32_t A[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) A[w] = 0;
-    int32_t t = 0;                          // time relative to T_p
-    uint32_t st = LS_IDLE, tag = 0, lam = 0, my_p = 0;
+    int32_t t = 0;                          // time relative to T_p; = mu once the lane has its hit
+    uint32_t res = kResIdle, my_p = 0;
     uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
 #pragma unroll
     for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
-    unsigned long long steps_ref = 0, steps_exec = 0;
+    // steps of results that bypass the accumulators (lost, not found, longer than max_len); the steps
+    // of accumulated results follow from the sums at the end
+    unsigned long long extra_ref = 0, extra_exec = 0;
     uint32_t n_none = 0, n_capfail = 0;
     WaveQueue q{0, 0, true};
 #ifdef BSX_DIAG
-    unsigned long long dbg_iters = 0, dbg_service = 0, dbg_walks = 0, dbg_cs = 0, dbg_ct = 0;
+    unsigned long long dbg_iters = 0, dbg_service = 0;
 #endif
 
-#ifdef BSX_DIAG
-    const unsigned long long c_loop = __builtin_readcyclecounter();
-#endif
-    const uint32_t* cbase = lc + kCacheHeaderWords;
-    // probe of state s: (hit, tag, length); key words are not needed until the kernel ends
-    auto probe = [&](const uint32_t (&s)[NW], uint32_t& tag_o, uint32_t& len_o) -> bool {
+    // probe of state s: is it a cached cycle state?  -> the entry's tag word (0 = no)
+    auto probe = [&](const uint32_t (&s)[NW]) -> uint32_t {
         uint32_t h = hash_state<NW>(s) & cmask;
         const uint32_t* e = cbase + h * S;
-        uint32_t et, el;
-        bool same;
+        uint32_t et, d;
+        // (the asm keeps the unused last word alive: a 16-byte ds_read_b128 takes 4 LDS cycles, the
+        //  12-byte ds_read_b96 the compiler would narrow it to takes 8)
         if constexpr (NW == 1) {
-            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-            same = v.x == s[0]; et = v.y; el = v.z;
+            uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+            asm volatile("" : "+v"(v.z), "+v"(v.w));
+            d = v.x ^ s[0]; et = v.y;
         } else if constexpr (NW == 2) {
-            const uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-            same = ((v.x ^ s[0]) | (v.y ^ s[1])) == 0; et = v.z; el = v.w;     // no short circuit: one 16-byte read
+            uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+            asm volatile("" : "+v"(v.w));
+            d = (v.x ^ s[0]) | (v.y ^ s[1]); et = v.z;          // one 16-byte read, no short circuit
         } else {
-            uint32_t d = 0;
+            d = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) d |= e[w] ^ s[w];
-            same = d == 0; et = e[NW]; el = e[NW + 1];
+            et = e[NW];
         }
-        bool hit = ((et & kTagMask) - 1u < vis) & same;     // tag in 1..vis
+        bool hit = (d == 0) & (et != 0);
         bool walking = (et >> 31) != 0 && !hit;             // a later insert skipped over this slot
         if (__builtin_expect(__ballot(walking) != 0, 0)) {          // collision chain: rare
-#ifdef BSX_DIAG
-            ++dbg_walks;
-#endif
             while (walking) {
                 h = (h + 1) & cmask;
                 const uint32_t* f = cbase + h * S;
-                uint32_t d = 0;
+                uint32_t d2 = 0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) d |= f[w] ^ s[w];
+                for (int w = 0; w < NW; ++w) d2 |= f[w] ^ s[w];
                 const uint32_t ft = f[NW];
-                const bool here = ((ft & kTagMask) - 1u < vis) & (d == 0);
-                if (here) { hit = true; et = ft; el = f[NW + 1]; }
+                const bool here = (d2 == 0) & (ft != 0);
+                if (here) { hit = true; et = ft; }
                 walking = (ft >> 31) != 0 && !here;
             }
         }
-        et &= kTagMask;
-        tag_o = et; len_o = el;
-        return hit;
+        return hit ? et : 0u;
     };
 
     for (;;) {
-        const uint64_t running = __ballot(st == LS_RUN);
-        const uint64_t waiting = __ballot(st >= LS_HIT);
+        const uint64_t running = __ballot(res == 0);
         const bool work_left = q.more || q.next < q.end;
-        if (!running && !waiting && !work_left) break;
+        if (!running && !work_left && !__ballot(res != kResIdle)) break;
         const uint32_t n_free = 64u - (uint32_t)__popcll(running);
 #ifdef BSX_DIAG
         ++dbg_iters;
-        const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
         if ((work_left && n_free >= service_lanes) || !running) {
 #ifdef BSX_DIAG
             ++dbg_service;
 #endif
             // ---- service round: record results, hand lost problems over, refill
-            if (st == LS_HIT) {
-                const uint32_t mu = (uint32_t)t;
-                const bool found = mu <= cap_rel && lam <= cap_rel - mu;
-                const uint32_t traj = tp + mu;
-                const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
-                steps_exec += traj;
-                steps_ref += found ? (unsigned long long)(traj + lam) : 0ull;   // model.py:201
-                n_capfail += found ? 0u : 1u;
-                n_none += keep ? 0u : 1u;
-                if (P.per_problem) {
-                    ProblemRec32 r;
+            if (res != 0 && res != kResIdle) {
+                if (res == kResLost) {
+                    const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
+                    if (at < P.stragglers_cap) P.stragglers[at] = my_p;
+                    else atomicOr(&P.ctr->straggler_overflow, 1u);
+                    extra_exec += tp + (uint32_t)t;
+                } else {
+                    const uint32_t tg = res & kTagMask, mu = (uint32_t)t, traj = tp + mu;
+                    const uint32_t lam = lamtab[tg - 1];
+                    const bool found = mu <= cap_rel && lam <= cap_rel - mu;
+                    const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
+                    if (P.per_problem) {
+                        ProblemRec32 r;
 #pragma unroll
-                    for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
-                    if (keep) {     // the key sits behind any entry of the attractor; A is still on its cycle
-                        uint32_t h = hash_state<NW>(A) & cmask;
-                        for (;;) {
-                            const uint32_t* f = cbase + h * S;
-                            uint32_t d = 0;
+                        for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
+                        if (keep) {
 #pragma unroll
-                            for (int w = 0; w < NW; ++w) d |= f[w] ^ A[w];
-                            if ((f[NW] & kTagMask) == tag && d == 0) {
+                            for (int w = 0; w < NW; ++w) r.key[w] = keytab[(tg - 1) * NW + w];
+                        }
+                        r.length = keep ? lam : 0; r.trajectory_l = keep ? traj : 0; r.found = keep; r.pad = 0;
+                        P.per_problem[my_p] = r;
+                    }
+                    if (__builtin_expect(!keep, 0)) {
+                        ++n_none;
+                        n_capfail += found ? 0u : 1u;                       // these add max_t each at the end
+                        extra_exec += traj;
+                        extra_ref += found ? (unsigned long long)(traj + lam) : 0ull;   // model.py:201
+                    } else {
+                        const uint32_t sq = traj * traj;
+                        bool in_regs = false;
 #pragma unroll
-                                for (int w = 0; w < NW; ++w) r.key[w] = f[NW + 2 + w];
-                                break;
-                            }
-                            if (f[NW] == 0) break;          // cannot happen: the state was found before
-                            h = (h + 1) & cmask;
+                        for (int j = 0; j < kTagAcc; ++j) {
+                            const bool m = tg == (uint32_t)(j + 1) && tsl2[j] < kRegSumGuard;
+                            tcnt[j] += m ? 1u : 0u;
+                            tsl[j] += m ? traj : 0u;
+                            tsl2[j] += m ? sq : 0u;
+                            in_regs = in_regs || m;
+                        }
+                        if (!in_regs) {
+                            atomicAdd(&acc_cnt[tg - 1], 1u);
+                            atomicAdd(&acc_sl[tg - 1], (unsigned long long)traj);
+                            atomicAdd(&acc_sl2[tg - 1], (unsigned long long)sq);
                         }
                     }
-                    r.length = keep ? lam : 0; r.trajectory_l = keep ? traj : 0; r.found = keep; r.pad = 0;
-                    P.per_problem[my_p] = r;
                 }
-                const uint32_t sq = traj * traj;
-                bool in_regs = false;
-#pragma unroll
-                for (int j = 0; j < kTagAcc; ++j) {
-                    const bool m = keep && tag == (uint32_t)(j + 1) && tsl2[j] < kRegSumGuard;
-                    tcnt[j] += m ? 1u : 0u;
-                    tsl[j] += m ? traj : 0u;
-                    tsl2[j] += m ? sq : 0u;
-                    in_regs = in_regs || m;
-                }
-                if (keep && !in_regs) {
-                    atomicAdd(&acc_cnt[tag - 1], 1u);
-                    atomicAdd(&acc_sl[tag - 1], (unsigned long long)traj);
-                    atomicAdd(&acc_sl2[tag - 1], (unsigned long long)sq);
-                }
-                st = LS_IDLE;
-            } else if (st == LS_LOST) {
-                const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
-                if (at < P.stragglers_cap) P.stragglers[at] = my_p;
-                else atomicOr(&P.ctr->straggler_overflow, 1u);
-                steps_exec += tp + (uint32_t)t;
-                st = LS_IDLE;
+                res = kResIdle;
             }
             if (work_left) {
                 if (q.next == q.end) {
@@ -210,105 +208,64 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
                     else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
                 }
                 const uint64_t avail = q.end - q.next;
-                const uint64_t idle = __ballot(st == LS_IDLE);
+                const uint64_t idle = __ballot(res == kResIdle);
                 if (avail && idle) {
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
-                    if (st == LS_IDLE && rank < avail) {
+                    if (res == kResIdle && rank < avail) {
                         my_p = (uint32_t)(q.next + rank);
                         init_problem_simple<NW>(P.sp, (uint64_t)my_p, A);
                         t = -(int32_t)tp;
-                        st = LS_RUN;
-                        if (!has_warmup) {              // s(T_p) = s(0) itself may be a cycle state: mu = 0
-                            uint32_t g0, l0;
-                            if (probe(A, g0, l0)) { st = LS_HIT; tag = g0; lam = l0; }
-                        }
+                        res = has_warmup ? 0u : probe(A);       // s(T_p) = s(0) itself may be a cycle state: mu = 0
                     }
                     const uint64_t n_idle = (uint64_t)__popcll(idle);
                     q.next += n_idle < avail ? n_idle : avail;
                 }
             }
         }       // no `continue`: one back edge keeps the loop-carried registers in place (no copy chains)
-#ifdef BSX_DIAG
-        const unsigned long long c1 = __builtin_readcyclecounter();
-        dbg_cs += c1 - c0;
-#endif
 
         // ---- one step for every running lane, then the lookup of the new state.  Waiting and idle lanes
         //      are masked off: their LDS reads would only add bank conflicts.
-        if (st == LS_RUN) {
-            uint32_t nxt[NW], g, l;
+        if (res == 0) {
+            uint32_t nxt[NW];
             net_step<NW, K>(nv, A, fm0, fv0, nxt);
             ++t;
             if (has_warmup) {
                 if (t <= 0) apply_perturbations<NW>(P.sp, (uint32_t)((int32_t)tp + t), 0ull, nxt);
             }
-            const bool hit = probe(nxt, g, l) && t >= 0;
-            const bool lost = !hit && t >= (int32_t)fast_steps;
+            uint32_t et = probe(nxt);
+            if (has_warmup) et = t >= 0 ? et : 0u;          // states before T_p do not count
 #pragma unroll
             for (int w = 0; w < NW; ++w) A[w] = nxt[w];
-            tag = hit ? g : tag;
-            lam = hit ? l : lam;
-            st = hit ? (uint32_t)LS_HIT : (lost ? (uint32_t)LS_LOST : (uint32_t)LS_RUN);
+            res = et ? et : (t >= fast_steps ? kResLost : 0u);
         }
-#ifdef BSX_DIAG
-        dbg_ct += __builtin_readcyclecounter() - c1;
-#endif
     }
 
-#ifdef BSX_DIAG
-    const unsigned long long c_end = __builtin_readcyclecounter();
-#endif
-    // ---- epilogue: per-lane sums -> wave table -> HBM log; workgroup accumulators -> HBM log
-    TableSlot<NW> slot;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) slot.key[w] = 0;
-    slot.length = 0; slot.count = 0; slot.sum_l = 0; slot.sum_l2 = 0;
+    // ---- epilogue: per-lane sums -> workgroup accumulators -> one log record per attractor and workgroup
 #pragma unroll
     for (int j = 0; j < kTagAcc; ++j) {
-        if (!__ballot(tcnt[j] != 0)) continue;
-        uint32_t k[NW], len = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) k[w] = 0;
-        for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
-            if ((cbase[sl * S + NW] & kTagMask) == (uint32_t)(j + 1)) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) k[w] = cbase[sl * S + NW + 2 + w];
-                len = cbase[sl * S + NW + 1];
-                break;
-            }
+        if (tcnt[j]) {
+            atomicAdd(&acc_cnt[j], tcnt[j]);
+            atomicAdd(&acc_sl[j], (unsigned long long)tsl[j]);
+            atomicAdd(&acc_sl2[j], (unsigned long long)tsl2[j]);
         }
-        table_merge<NW>(P, slot, lane, tcnt[j] != 0, k, len, tcnt[j], (uint64_t)tsl[j], (uint64_t)tsl2[j]);
     }
-    if (slot.count) log_append<NW>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
     __syncthreads();
     for (uint32_t a = threadIdx.x; a < kAccs; a += blockDim.x) {
         const uint32_t cn = acc_cnt[a];
         if (!cn) continue;
-        for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
-            if ((cbase[sl * S + NW] & kTagMask) == a + 1) {
-                uint32_t k[NW];
+        uint32_t k[NW];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) k[w] = cbase[sl * S + NW + 2 + w];
-                log_append<NW>(P, k, cbase[sl * S + NW + 1], cn, (uint64_t)acc_sl[a], (uint64_t)acc_sl2[a]);
-                break;
-            }
-        }
+        for (int w = 0; w < NW; ++w) k[w] = keytab[a * NW + w];
+        const unsigned long long sl = acc_sl[a];
+        log_append<NW>(P, k, lamtab[a], cn, sl, acc_sl2[a]);
+        extra_exec += sl;                                                       // sum of T_p + mu
+        extra_ref += sl + (unsigned long long)cn * lamtab[a];                   // + lambda each (model.py:201)
     }
 #ifdef BSX_DIAG
-    if (lane == 0) {
-        atomicAdd(&P.ctr->wave_iters, dbg_iters);
-        atomicAdd(&P.ctr->service_rounds, dbg_service);
-        atomicAdd(&P.ctr->pad, (unsigned int)dbg_walks);        // iterations that entered a collision-chain walk
-        atomicAdd(&P.ctr->cycles_service, dbg_cs);
-        atomicAdd(&P.ctr->cycles_step, dbg_ct);
-        atomicAdd(&P.ctr->cycles_wave, __builtin_readcyclecounter() - c_begin);
-        atomicAdd(&P.ctr->n_waves, 1ull);
-        atomicAdd(&P.ctr->cycles_prologue, c_loop - c_begin);
-        atomicAdd(&P.ctr->cycles_epilogue, __builtin_readcyclecounter() - c_end);
-    }
+    if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_service); }
 #endif
-    wave_atomic_add(&P.ctr->steps_ref, steps_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), lane);
-    wave_atomic_add(&P.ctr->steps_exec, steps_exec, lane);
+    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), lane);
+    wave_atomic_add(&P.ctr->steps_exec, extra_exec, lane);
     wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, lane);
 }
 
