@@ -276,6 +276,30 @@ def test_lean_kernel_stragglers_and_fallback(eng):
     _same_attract(eng, orc, (1 << 20), 1 << 14, 30, 1)
 
 
+def _identity_yaml(n, period2=()):
+    """x_i' = x_i (every state a fixed point), except the pairs in `period2`, which swap (cycles of length 2)."""
+    rule = {i: i for i in range(n)}
+    for a, b in period2:
+        rule[a], rule[b] = b, a
+    lines = ['nodes:'] + ['    - x{}'.format(i) for i in range(n)]
+    lines += ['update rules:'] + ['    x{}: x{}'.format(i, rule[i]) for i in range(n)]
+    lines += ['initial state:'] + ['    x{}: any'.format(i) for i in range(n)]
+    return '\n'.join(lines) + '\n'
+
+
+def test_more_attractors_than_the_lean_kernel_resolves(eng):
+    # 2^14 attractors: the cycle cache holds a few hundred states, the lean kernel's accumulators 64
+    # attractors; everything else must come back through the straggler list / the detector
+    cfg, net, space, orc = _setup(eng, _identity_yaml(14), Mode.ATTRACT, math.inf)
+    r = _same_attract(eng, orc, 0, 1 << 14, None)
+    assert len(r.table) == 1 << 14
+    # 2^12 fixed points + (2^14 - 2^12) / 2 two-cycles: keys are the smaller state of each pair
+    cfg, net, space, orc = _setup(eng, _identity_yaml(14, period2=[(3, 9)]), Mode.ATTRACT, math.inf)
+    r = _same_attract(eng, orc, 0, 1 << 14, None)
+    assert len(r.table) == (1 << 13) + (1 << 12)
+    _same_attract(eng, orc, 0, 1 << 14, None)          # again, with whatever the cache learnt
+
+
 def test_attract_with_fixed_node_variations_uses_detector_only(eng):
     # not reachable through the YAML front end (attract forbids variations) but allowed by the C-ABI:
     # cycles differ per fixed-node variant, so the cycle cache must stay out of it
