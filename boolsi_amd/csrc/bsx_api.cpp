@@ -389,6 +389,23 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     h->fast_ok = true;
     sp.n_any = n_any;
     sp.identity_any = identity ? 1 : 0;
+    // deposit plan for scattered 'any' nodes: runs of consecutive nodes inside one 32-bit state word
+    sp.n_runs = 0;
+    if (!identity && n_any && n_any <= 64) {
+        std::vector<uint32_t> plan;
+        uint32_t j = 0;
+        while (j < n_any) {
+            uint32_t len = 1;
+            while (j + len < n_any && any[j + len] == any[j] + len && ((any[j] + len) >> 5) == (any[j] >> 5)) ++len;
+            plan.push_back(j | (any[j] >> 5) << 8 | (any[j] & 31u) << 16);
+            plan.push_back(len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u);
+            j += len;
+        }
+        if (plan.size() <= 2 * kMaxDepositRuns) {
+            sp.n_runs = (uint32_t)(plan.size() / 2);
+            std::copy(plan.begin(), plan.end(), sp.deposit);
+        }
+    }
     sp.n_fv = n_fixed_var;
     sp.n_pv = n_pert_var;
     sp.tp_origin = tp_origin;
@@ -569,8 +586,9 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // Fast path: simple enumeration (no variations, 'any' nodes = nodes 0..a-1, a <= 64), no warm-up,
     // cycle cache on.  [discovery prefix with the detector] -> lean kernel -> stragglers.
     // (a short uniform warm-up is fine; its length enters the lean kernel's 32-bit sums of trajectory_l^2)
-    const bool simple = h->sp.identity_any && h->sp.n_any <= 64 && !h->sp.n_fv && !h->sp.n_pv && h->sp.tp_origin <= 200;
+    const bool simple = h->sp.n_any <= 64 && (h->sp.identity_any || h->sp.n_runs) && !h->sp.n_fv && !h->sp.n_pv && h->sp.tp_origin <= 200;
     bool use_fast = P.cc.enabled && simple && h->fast_ok && count >= kFastMinProblems;
+    if (const char* e = std::getenv("BSX_LEAN")) use_fast = use_fast && std::atoi(e) != 0;      // tuning / test knob
     if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] attract: count %llu cache %u identity %u n_any %u n_fv %u n_pv %u tp %u fast_ok %d -> lean path %d\n", (unsigned long long)count, P.cc.enabled, h->sp.identity_any, h->sp.n_any, h->sp.n_fv, h->sp.n_pv, h->sp.tp_origin, (int)h->fast_ok, (int)use_fast);
     uint64_t done = 0;
     if (use_fast) {

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
     const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
-    const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
+    const bool simple_space = bsx::simple_space(P.sp);
     const bool use_cache = P.cc.enabled != 0;
     const uint32_t fast_steps = P.fast_steps;
     const uint32_t service_lanes = kServiceLanes;

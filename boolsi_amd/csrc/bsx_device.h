@@ -13,6 +13,7 @@ constexpr int kTableSlots = 64;             // per-wave attractor table: one slo
 constexpr uint32_t kStepLimit = 1u << 30;   // internal per-trajectory step limit (u32 counters)
 constexpr uint64_t kDigestSeed = 0xCBF29CE484222325ull;
 constexpr uint64_t kDigestPrime = 0x100000001B3ull;
+constexpr uint32_t kMaxDepositRuns = 12;
 
 // Network tables in HBM (staged into LDS by each workgroup where they fit).
 struct DevNet {
@@ -36,6 +37,12 @@ struct DevSpace {
     uint32_t fixval[kMaxW32];
     uint32_t n_any;
     uint32_t identity_any;          // any-nodes are exactly nodes 0..n_any-1: digits deposit = OR
+    // n_any <= 64 and the 'any' nodes form at most kMaxDepositRuns runs of consecutive nodes within one
+    // 32-bit state word: the digits are deposited run by run (shift, mask, or) instead of bit by bit.
+    // run r: digits [src, src + len) -> bits [shift, shift + len) of word `word`;
+    // deposit[2r] = src | word << 8 | shift << 16, deposit[2r + 1] = ((1 << len) - 1)
+    uint32_t n_runs;                // 0 = no run plan (identity spaces do not need one)
+    uint32_t deposit[2 * 12];
     uint32_t n_fv;
     uint32_t n_pv;
     uint32_t tp_origin;             // last origin perturbation time (0 = none)

@@ -677,14 +677,29 @@ __device__ __forceinline__ void cache_publish(const CycleCache& cc, const uint32
     }
 }
 
-// Enumeration fast path: no variations, 'any' nodes = nodes 0..n_any-1 with n_any <= 64.
+// Enumeration fast path: no variations, at most 64 'any' nodes that are either nodes 0..n_any-1 or a
+// few runs of consecutive nodes (simple_space below).
 template <int NW>
 __device__ __forceinline__ void init_problem_simple(const DevSpace& sp, uint64_t p, uint32_t (&s)[NW]) {
     const uint64_t d = sp.first_digits[0] + p;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s[w] = sp.origin[w];
-    s[0] |= (uint32_t)d;
-    if constexpr (NW > 1) s[1] |= (uint32_t)(d >> 32);
+    if (sp.identity_any) {
+        s[0] |= (uint32_t)d;
+        if constexpr (NW > 1) s[1] |= (uint32_t)(d >> 32);
+    } else {
+        for (uint32_t r = 0; r < sp.n_runs; ++r) {          // uniform trip count and run descriptors
+            const uint32_t desc = sp.deposit[2 * r], mask = sp.deposit[2 * r + 1];
+            const uint32_t piece = ((uint32_t)(d >> (desc & 63u)) & mask) << ((desc >> 16) & 31u);
+            const uint32_t word = (desc >> 8) & 7u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s[w] |= (word == (uint32_t)w) ? piece : 0u;
+        }
+    }
+}
+
+__device__ __forceinline__ bool simple_space(const DevSpace& sp) {
+    return sp.n_any <= 64 && (sp.identity_any || sp.n_runs) && !sp.n_fv && !sp.n_pv;
 }
 
 

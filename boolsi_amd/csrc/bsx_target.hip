@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
     uint32_t* smem_free;
     const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
-    const bool simple_space = P.sp.identity_any && P.sp.n_any <= 64 && !P.sp.n_fv && !P.sp.n_pv;
+    const bool simple_space = bsx::simple_space(P.sp);
 
     uint32_t A[NW], B[NW], fm[NW], fv[NW], tm[NW], tc[NW];
 #pragma unroll

@@ -31,6 +31,7 @@ def eng(request):
     from boolsi_amd.engine import Engine
     os.environ['BSX_CYCLE_CACHE'] = '1' if request.param == 'cycle_cache' else '0'
     e = Engine(0)
+    e.cycle_cache = request.param == 'cycle_cache'
     os.environ.pop('BSX_CYCLE_CACHE')
     yield e
     e.close()
@@ -298,6 +299,31 @@ def test_more_attractors_than_the_lean_kernel_resolves(eng):
     r = _same_attract(eng, orc, 0, 1 << 14, None)
     assert len(r.table) == (1 << 13) + (1 << 12)
     _same_attract(eng, orc, 0, 1 << 14, None)          # again, with whatever the cache learnt
+
+
+def test_scattered_any_nodes_take_the_lean_path(eng):
+    # 'any' nodes in five runs (one crossing the 32-bit word boundary, so six deposit runs), the rest
+    # constants: digits are deposited run by run; results must equal the oracle's bit-by-bit enumeration
+    any_nodes = set(range(2, 10)) | set(range(26, 37)) | {40} | set(range(44, 52)) | set(range(60, 64))
+    bits = synth.seeded_bits(64, 6401)
+    text = synth.network_yaml(64, 2, 64, initial={i: str(bits[i]) for i in range(64) if i not in any_nodes})
+    cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 4096)
+    assert space.n_problems == 1 << len(any_nodes)
+    r = _same_attract(eng, orc, 0, 1 << 15, 4096)
+    if eng.cycle_cache:
+        assert r.stats['kernel_launches'] >= 2          # discovery sample + lean kernel (+ stragglers)
+    _same_attract(eng, orc, (1 << 31) + 777, 1 << 15, 4096)
+    _same_attract(eng, orc, space.n_problems - 20000, 20000, 4096)
+    # too many runs for a deposit plan (every other node): generic enumeration, same answers
+    text = synth.network_yaml(64, 2, 64, initial={i: str(bits[i]) for i in range(64) if i % 2})
+    cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 4096)
+    _same_attract(eng, orc, 12345, 1 << 14, 4096)
+    # target mode shares the enumeration
+    tm, tc = code_to_words(0b1011 << 20, net.n_words), code_to_words(0b1001 << 20, net.n_words)
+    hits, _ = eng.target(999, 1 << 14, 200, tm, tc)
+    ref, _ = orc.target(999, 1 << 14, 200, tm, tc, n_threads=8)
+    want = np.nonzero(ref['reached'])[0]
+    assert np.array_equal(hits['offset'], want) and np.array_equal(hits['t'], ref['t_stop'][want])
 
 
 def test_attract_with_fixed_node_variations_uses_detector_only(eng):
