@@ -199,8 +199,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
                     q.next += n_idle < avail ? n_idle : avail;
                 }
             }
-            continue;       // re-evaluate the wave state (nothing to step if every lane is idle)
-        }
+        }       // no `continue`: a single back edge keeps the loop-carried registers in place (no copy chains)
 
         // ---- one network update per lane per iteration
         const bool step_b = (phase == PH_MU) && sub;
