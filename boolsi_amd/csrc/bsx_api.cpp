@@ -23,6 +23,7 @@ hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem,
 hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
 hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
 hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P);
+hipError_t launch_simulate_sliced64(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P);
 hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
 hipError_t configure_attract(int nw, int k, bool lds, size_t shmem);
@@ -863,13 +864,17 @@ static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, 
     P.final_states = d_final.p;
     P.ctr = h->d_ctr.p;
 
-    const size_t shmem = (size_t)rows * (8 + 128) * 4;
-    const uint64_t groups = (count + 2047) / 2048;
-    const uint64_t per_cu = std::max<size_t>(1, (160 * 1024) / shmem);
+    // K <= 3 and n <= 128: second-generation kernel (8-byte rows, constants in registers); BSX_SLICED=1 keeps the first
+    const char* sl_env = std::getenv("BSX_SLICED");
+    const bool gen2 = K <= 3 && rows <= 128 && !(sl_env && sl_env[0] == '1');
+    const size_t shmem = gen2 ? (size_t)rows * 1024 + (4096 + 64) * 4 : (size_t)rows * (8 + 128) * 4;
+    const uint64_t groups = gen2 ? (count + 4095) / 4096 : (count + 2047) / 2048;
+    const uint64_t per_cu = gen2 ? 1 : std::max<size_t>(1, (160 * 1024) / shmem);
     const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)h->prop.multiProcessorCount * per_cu));
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_simulate_sliced((int)h->net.nw, (int)K, dim3((uint32_t)blocks), shmem, h->stream, P));
+    if (gen2) HIPCHK(h, launch_simulate_sliced64((int)h->net.nw, (int)K, dim3((uint32_t)blocks), shmem, h->stream, P));
+    else HIPCHK(h, launch_simulate_sliced((int)h->net.nw, (int)K, dim3((uint32_t)blocks), shmem, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     Counters ctr{};
     HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));

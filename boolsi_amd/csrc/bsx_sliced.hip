@@ -130,6 +130,175 @@ __global__ __launch_bounds__(64 * kSlicedWaves) void k_simulate_sliced(const Sli
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second generation for K <= 3 and n <= 128 (config 5's shape): the per-row constants never change
+// during a run, so each wave keeps them in registers for the whole launch.
+//   * workgroup = 16 waves on one CU, group = 4096 trajectories; lane l owns trajectories 64l..64l+63 as
+//     one 8-byte element per row, so a row is 512 contiguous bytes and every access is a conflict-free
+//     ds_read_b64 / ds_write_b64 (256 B/clk instead of 128 for the 4-byte rows of the kernel above);
+//   * wave v evaluates rows [v*R/16, (v+1)*R/16), at most 8: per row K LDS byte addresses and 2^K leaf
+//     words (truth-table bits as all-ones / all-zeros) live in VGPRs -- a step is K reads, 2^K - 1
+//     v_bfi per 32 trajectories and one write per row, no descriptor traffic, no address arithmetic;
+//   * the two state buffers are interleaved row by row (row i: 512 B of buffer 0, 512 B of buffer 1),
+//     so "the other buffer" is the immediate offset 512 and the step loop is unrolled by two instead
+//     of swapping pointers (a buffer of n = 128 rows is 64 KiB, beyond the 16-bit ds offset).
+constexpr int kS64Waves = 16;
+constexpr int kS64RowsPerWave = 8;
+constexpr uint32_t kS64Group = 4096;
+constexpr uint32_t kS64RowBytes = 1024;
+
+__device__ __forceinline__ uint32_t s64_skew(uint32_t k) { return k + (k >> 6); }   // scratch index, conflict-free column reads
+
+template <int K, uint32_t RD, uint32_t WR>
+__device__ __forceinline__ void s64_step(const uint32_t (&addr)[kS64RowsPerWave][K],
+                                         const uint32_t (&leaf)[kS64RowsPerWave][1 << K], uint32_t out_addr,
+                                         uint32_t rpw) {
+    typedef const bsx_u32x2 __attribute__((address_space(3))) lds_rd;
+    typedef bsx_u32x2 __attribute__((address_space(3))) lds_wr;
+#pragma unroll
+    for (int r0 = 0; r0 < kS64RowsPerWave; r0 += 2) {
+        if ((uint32_t)r0 >= rpw) break;                 // uniform
+        bsx_u32x2 g[2][K];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < K; ++j) g[u][j] = *reinterpret_cast<lds_rd*>(addr[r0 + u][j] + RD);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = r0 + u;
+            uint32_t x[1 << (K - 1)], y[1 << (K - 1)];
+#pragma unroll
+            for (int i = 0; i < (1 << (K - 1)); ++i) {
+                x[i] = bfi(g[u][0].x, leaf[r][2 * i + 1], leaf[r][2 * i]);
+                y[i] = bfi(g[u][0].y, leaf[r][2 * i + 1], leaf[r][2 * i]);
+            }
+#pragma unroll
+            for (int j = 1; j < K; ++j)
+#pragma unroll
+                for (int i = 0; i < (1 << (K - 1 - j)); ++i) {
+                    x[i] = bfi(g[u][j].x, x[2 * i + 1], x[2 * i]);
+                    y[i] = bfi(g[u][j].y, y[2 * i + 1], y[2 * i]);
+                }
+            bsx_u32x2 o;
+            o.x = x[0]; o.y = y[0];
+            if ((uint32_t)r < rpw) *reinterpret_cast<lds_wr*>(out_addr + (uint32_t)r * kS64RowBytes + WR) = o;     // uniform
+        }
+    }
+}
+
+template <int NW, int K>
+__global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const SlicedParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    // absolute LDS addressing (as net_step): the dynamic block must start at LDS address 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)smem != 0u) __builtin_trap();
+    // (readfirstlane tells the compiler the wave index is uniform)
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n = P.n_nodes, rows = P.n_rows;          // rows: multiple of 16, <= 128
+    const uint32_t rpw = rows / kS64Waves;
+    const uint32_t scratch = rows * kS64RowBytes;           // byte address of the transposition scratch
+
+    // ---- per-wave constants
+    uint32_t addr[kS64RowsPerWave][K], leaf[kS64RowsPerWave][1 << K];
+#pragma unroll
+    for (int r = 0; r < kS64RowsPerWave; ++r) {
+        const uint32_t row = wave * rpw + (uint32_t)r;
+        const bool live = (uint32_t)r < rpw;
+        const uint32_t* d = P.desc + (size_t)(live ? row : 0) * 8;
+#pragma unroll
+        for (int j = 0; j < K; ++j) addr[r][j] = d[j] * kS64RowBytes + lane * 8u;
+        const uint32_t tt = live ? d[6] : 0u;               // 2^K <= 8 table bits
+#pragma unroll
+        for (int i = 0; i < (1 << K); ++i) leaf[r][i] = 0u - ((tt >> i) & 1u);
+    }
+    const uint32_t out_addr = wave * rpw * kS64RowBytes + lane * 8u;
+
+    const uint64_t n_groups = (P.count + kS64Group - 1) / kS64Group;
+    for (uint64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        const uint64_t base = group * kS64Group;
+        // ---- initial states into buffer 0, one 32-node word at a time through the scratch
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x) {
+                Problem<NW> pr;
+                pr.s[w] = 0;
+                if (base + k < P.count) init_problem<NW>(P.sp, base + k, pr);
+                *reinterpret_cast<lds_u32*>(scratch + s64_skew(k) * 4u) = pr.s[w];
+            }
+            __syncthreads();
+            for (uint32_t b = wave * 2; b < wave * 2 + 2; ++b) {        // 16 waves x 2 = the word's 32 nodes
+                const uint32_t node = (uint32_t)w * 32 + b;
+                if (node >= rows) break;
+                uint32_t lo = 0, hi = 0;
+                if (node < n) {
+                    for (uint32_t k = 0; k < 32; ++k) {
+                        lo |= ((*reinterpret_cast<lds_u32*>(scratch + s64_skew(lane * 64 + k) * 4u) >> b) & 1u) << k;
+                        hi |= ((*reinterpret_cast<lds_u32*>(scratch + s64_skew(lane * 64 + 32 + k) * 4u) >> b) & 1u) << k;
+                    }
+                }
+                *reinterpret_cast<lds_u32*>(node * kS64RowBytes + lane * 8u) = lo;
+                *reinterpret_cast<lds_u32*>(node * kS64RowBytes + lane * 8u + 4u) = hi;
+            }
+        }
+        __syncthreads();
+
+        // ---- T synchronous updates, buffer parity = (t - 1) & 1
+        uint32_t sched_at = 0;
+        uint64_t next_t = P.n_sched ? (uint64_t)P.sched[0] : ~0ull;
+        for (uint64_t t = 1; t <= P.max_t; ++t) {
+            const bool odd = (t & 1ull) != 0;               // odd steps read buffer 0 and write buffer 1
+            if (odd) s64_step<K, 0u, 512u>(addr, leaf, out_addr, rpw);
+            else s64_step<K, 512u, 0u>(addr, leaf, out_addr, rpw);
+            // perturbation override at time t (model.py:68-71): whole rows of the buffer just written.
+            // Every wave walks the (uniform) schedule and the wave that owns the row overwrites what it
+            // has just stored, so the step's one barrier covers the override too.
+            while (next_t <= t) {
+                if (next_t == t) {
+                    const uint32_t node = P.sched[3 * sched_at + 1];
+                    if (node - wave * rpw < rpw) {
+                        const uint32_t v = P.sched[3 * sched_at + 2] ? 0xFFFFFFFFu : 0u;
+                        const uint32_t a = node * kS64RowBytes + (odd ? 512u : 0u) + lane * 8u;
+                        *reinterpret_cast<lds_u32*>(a) = v;
+                        *reinterpret_cast<lds_u32*>(a + 4u) = v;
+                    }
+                }
+                ++sched_at;
+                next_t = sched_at < P.n_sched ? (uint64_t)P.sched[3 * sched_at] : ~0ull;
+            }
+            __syncthreads();
+        }
+        const uint32_t cur = (P.max_t & 1ull) ? 512u : 0u;      // buffer holding s(max_t)
+
+        // ---- final states: thread handles trajectories tid, tid + 1024, ...
+        for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x) {
+            if (base + k >= P.count) break;
+            const uint32_t src = (k >> 6) * 8u + ((k >> 5) & 1u) * 4u + cur, bit = k & 31u;
+            uint32_t s[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                uint32_t word = 0;
+                for (uint32_t b = 0; b < 32; ++b) {
+                    const uint32_t node = (uint32_t)w * 32 + b;
+                    if (node < n) word |= ((*reinterpret_cast<lds_u32*>(node * kS64RowBytes + src) >> bit) & 1u) << b;
+                }
+                s[w] = word;
+            }
+#pragma unroll
+            for (int w = 0; w < (NW + 1) / 2; ++w) {
+                uint64_t word = s[2 * w];
+                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                if ((uint32_t)w < P.w64) P.final_states[(base + k) * P.w64 + w] = word;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        atomicAdd(&P.ctr->steps_ref, (unsigned long long)(P.count * P.max_t));
+        atomicAdd(&P.ctr->steps_exec, (unsigned long long)(P.count * P.max_t));
+    }
+}
+
 template <int NW, int K>
 static hipError_t launch_sliced_nk(bool, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
     hipError_t e = hipFuncSetAttribute((const void*)k_simulate_sliced<NW, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -138,10 +307,33 @@ static hipError_t launch_sliced_nk(bool, dim3 grid, size_t shmem, hipStream_t st
     return hipGetLastError();
 }
 
+template <int NW, int K>
+static hipError_t launch_sliced64_nk(dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_simulate_sliced64<NW, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_simulate_sliced64<NW, K>), grid, dim3(64 * kS64Waves), shmem, st, P);
+    return hipGetLastError();
+}
 
 hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
     const bool lds = true;
     BSX_DISPATCH(launch_sliced_nk)
+}
+
+// K <= 3, n <= 128 (rows a multiple of 16): shmem = rows * 1024 + (4096 + 64) * 4 bytes, one workgroup per CU
+hipError_t launch_simulate_sliced64(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
+    switch (nw * 8 + k) {
+        case 1 * 8 + 1: return launch_sliced64_nk<1, 1>(grid, shmem, st, P);
+        case 1 * 8 + 2: return launch_sliced64_nk<1, 2>(grid, shmem, st, P);
+        case 1 * 8 + 3: return launch_sliced64_nk<1, 3>(grid, shmem, st, P);
+        case 2 * 8 + 1: return launch_sliced64_nk<2, 1>(grid, shmem, st, P);
+        case 2 * 8 + 2: return launch_sliced64_nk<2, 2>(grid, shmem, st, P);
+        case 2 * 8 + 3: return launch_sliced64_nk<2, 3>(grid, shmem, st, P);
+        case 4 * 8 + 1: return launch_sliced64_nk<4, 1>(grid, shmem, st, P);
+        case 4 * 8 + 2: return launch_sliced64_nk<4, 2>(grid, shmem, st, P);
+        case 4 * 8 + 3: return launch_sliced64_nk<4, 3>(grid, shmem, st, P);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace bsx

@@ -359,6 +359,9 @@ def test_largest_network_and_rule_width(eng):
                                              fixed={3: '1', 17: '0'},
                                              perturbations={5: {'1': '2, 6-7, 90'}, 30: {'0': '3, 64'}}), 128, 12345, 6000),
     ('n64_k1', synth.network_yaml(64, 1, 641), 64, 0, 2048),
+    ('n48_k3_odd_t', synth.network_yaml(48, 3, 483, fixed={7: '1'}, perturbations={9: {'0': '5, 33'}}), 101, 3, 9000),
+    ('n20_k2', synth.network_yaml(20, 2, 202), 33, 1000, 4097),
+    ('n128_k3', synth.network_yaml(128, 3, 1283), 257, (1 << 100) + 1, 8192),
     ('n250_k4', synth.network_yaml(250, 4, 2504), 70, (1 << 249) - 5000, 3000),
 ], ids=lambda v: v if isinstance(v, str) and len(v) < 30 else None)
 def test_sliced_simulate_matches_oracle_and_per_lane_kernel(eng, name, text, max_t, first, count):
@@ -373,3 +376,9 @@ def test_sliced_simulate_matches_oracle_and_per_lane_kernel(eng, name, text, max
     finally:
         os.environ.pop('BSX_SLICED')
     assert np.array_equal(final, final2)
+    os.environ['BSX_SLICED'] = '1'            # first-generation sliced kernel (what n > 128 or K > 3 get anyway)
+    try:
+        _, final3, _, _ = eng.simulate(first, count, max_t, trajectories=False, digest=False)
+    finally:
+        os.environ.pop('BSX_SLICED')
+    assert np.array_equal(final, final3)
