@@ -70,32 +70,37 @@ class Comm:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return [int(v) for v in t.tolist()]
 
-    def allgather_records(self, records):
+    def allgather_records(self, records, expect=64):
         """
         All-gather a 1-D numpy structured array (e.g. _lib.ATTR_REC) -> list of per-rank arrays.
-        One collective for the counts, one for the records padded to the common maximum.
+        One collective when every rank has at most `expect` records (the usual case: a handful of
+        attractors): each rank sends an 8-byte count followed by `expect` record slots.  If some rank has
+        more, every rank sees that in the counts and a second collective moves the records padded to the
+        common maximum.
         """
         if self.world == 1:
             return [records]
         torch, dist = self._torch, self._dist
         dev = self._device()
-        n = torch.tensor([len(records)], dtype=torch.int64, device=dev)
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-        dist.all_gather(counts, n)
-        counts = [int(c.item()) for c in counts]
-        cap = max(max(counts), 1)
         item = records.dtype.itemsize
-        buf = np.zeros(cap * item, np.uint8)
-        buf[:len(records) * item] = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
-        mine = torch.from_numpy(buf).to(dev)
-        gathered = torch.empty(self.world * cap * item, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, mine)
-        host = gathered.cpu().numpy()
-        out = []
-        for r, c in enumerate(counts):
-            chunk = host[r * cap * item:(r * cap + c) * item]
-            out.append(np.frombuffer(chunk.tobytes(), dtype=records.dtype))
-        return out
+        raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+
+        def exchange(cap):
+            buf = np.zeros(8 + cap * item, np.uint8)
+            buf[:8] = np.frombuffer(np.uint64(len(records)).tobytes(), np.uint8)
+            n = min(len(records), cap) * item
+            buf[8:8 + n] = raw[:n]
+            mine = torch.from_numpy(buf).to(dev)
+            gathered = torch.empty(self.world * buf.size, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(gathered, mine)
+            host = gathered.cpu().numpy().reshape(self.world, buf.size)
+            counts = [int(np.frombuffer(host[r, :8].tobytes(), np.uint64)[0]) for r in range(self.world)]
+            return host, counts
+
+        host, counts = exchange(expect)
+        if max(counts) > expect:
+            host, counts = exchange(max(counts))
+        return [np.frombuffer(host[r, 8:8 + c * item].tobytes(), dtype=records.dtype) for r, c in enumerate(counts)]
 
     def gather_concat(self, array):
         """All-gather a numpy array along axis 0 (rank order = index order for range partitions)."""

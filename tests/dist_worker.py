@@ -37,11 +37,13 @@ def main():
     mine2d = np.arange(first, first + count, dtype=np.uint64).reshape(-1, 1).repeat(3, axis=1)[: (comm.rank + 1) * 5]
     joined = comm.gather_concat(mine2d)
     empty = comm.gather_concat(np.zeros((0, 2), np.uint32))
+    # one rank with more rows than the single-collective fast path carries: second collective
+    big = comm.gather_concat(np.arange(comm.rank * 1000, comm.rank * 1000 + (300 if comm.rank == 1 else 3), dtype=np.uint64))
     comm.barrier()
     with open('{}.{}'.format(out_path, comm.rank), 'w') as f:
         json.dump({'rank': comm.rank, 'world': comm.world, 'first': first, 'count': count,
                    'merged': {str(k): v for k, v in merged.items()}, 'none': none_all, 'steps': steps_all,
-                   'slowest': slowest, 'joined': joined.tolist(), 'empty_shape': list(empty.shape), 'per_rank_counts': [len(g) for g in gathered]}, f)
+                   'slowest': slowest, 'joined': joined.tolist(), 'empty_shape': list(empty.shape), 'big': big.tolist(), 'per_rank_counts': [len(g) for g in gathered]}, f)
     comm.shutdown()
 
 

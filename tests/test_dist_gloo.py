@@ -72,4 +72,5 @@ def test_gloo_allgather_merge_equals_single_process(tmp_path, world):
             lo, cnt = partition(20013, world, q)
             expect_joined += [[v, v, v] for v in range(lo, lo + cnt)][: (q + 1) * 5]
         assert r['joined'] == expect_joined and r['empty_shape'] == [0, 2]
+        assert r['big'] == [v for q in range(world) for v in range(q * 1000, q * 1000 + (300 if q == 1 else 3))]
     assert sum(r['count'] for r in results) == 20013
