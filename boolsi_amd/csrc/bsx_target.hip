@@ -68,36 +68,38 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
                 const uint64_t n_idle = (uint64_t)__popcll(idle);
                 q.next += n_idle < avail ? n_idle : avail;
             }
-            continue;
-        }
+        }       // no `continue`: a single back edge keeps the loop-carried registers in place
 
-        // ---- check the current state (covers s(T_p), model.py:200), then one network update
-        uint32_t nxt[NW];
-        net_step<NW, K>(nv, A, fm, fv, nxt);
-        if (phase == PH_BRENT) {
-            const bool reached = target_hit<NW>(A, tm, tc);
-            const bool capped = !reached && t >= t_cap;
-            const uint32_t lam1 = lam + 1;
-            const bool closed = !reached && !capped && eq_words<NW>(nxt, B);     // every state has been checked
-            const bool tele = !closed && lam1 == power;
-            if (reached | capped | closed) {
-                P.t_hit[my_p] = reached ? t : kNotReached;
-                n_hits += reached ? 1u : 0u;
-                limit_hits += (capped && t_cap == kStepLimit) ? 1u : 0u;
-                steps_exec += t;
-                phase = PH_IDLE;
-            } else {
+        // ---- check the current state (covers s(T_p), model.py:200), then one network update; idle lanes
+        //      are masked off (their LUT reads would only add LDS bank conflicts)
+        if (phase >= PH_WARM) {
+            uint32_t nxt[NW];
+            net_step<NW, K>(nv, A, fm, fv, nxt);
+            if (phase == PH_BRENT) {
+                const bool reached = target_hit<NW>(A, tm, tc);
+                const bool capped = !reached && t >= t_cap;
+                const uint32_t lam1 = lam + 1;
+                const bool closed = !reached && !capped && eq_words<NW>(nxt, B);     // every state has been checked
+                const bool tele = !closed && lam1 == power;
+                if (reached | capped | closed) {
+                    P.t_hit[my_p] = reached ? t : kNotReached;
+                    n_hits += reached ? 1u : 0u;
+                    limit_hits += (capped && t_cap == kStepLimit) ? 1u : 0u;
+                    steps_exec += t;
+                    phase = PH_IDLE;
+                } else {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { A[w] = nxt[w]; B[w] = tele ? nxt[w] : B[w]; }
-                power = tele ? power << 1 : power;
-                lam = tele ? 0u : lam1;
+                    for (int w = 0; w < NW; ++w) { A[w] = nxt[w]; B[w] = tele ? nxt[w] : B[w]; }
+                    power = tele ? power << 1 : power;
+                    lam = tele ? 0u : lam1;
+                    ++t;
+                }
+            } else if (phase == PH_WARM) {
                 ++t;
+                apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
+                copy_words<NW>(A, nxt);
+                if (t == tp) { phase = PH_BRENT; lam = 0; power = 1; copy_words<NW>(B, A); }
             }
-        } else if (phase == PH_WARM) {
-            ++t;
-            apply_perturbations<NW>(P.sp, t, pv_digits, nxt);
-            copy_words<NW>(A, nxt);
-            if (t == tp) { phase = PH_BRENT; lam = 0; power = 1; copy_words<NW>(B, A); }
         }
     }
     wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps_exec, lane);
