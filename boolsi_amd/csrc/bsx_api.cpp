@@ -79,6 +79,8 @@ struct bsx_engine {
     bool cache_enabled = true;
     int lean_blocks_per_cu = 0;  // occupancy of the lean attract kernel for the current network
     bool fast_ok = true;        // cleared when the lean kernel's straggler list overflowed for this space
+    uint32_t fast_steps = 0;    // lean kernel: steps without a cached cycle state before a problem is handed over (0 = default)
+    bool fast_calibrated = false;
     uint32_t cache_lds_slots = 0;
     DevBuf<CycleRecord> d_cc_journal;
     DevBuf<unsigned int> d_cc_claims;
@@ -388,6 +390,8 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_claims.p, 0, sizeof(unsigned int) * kCycleClaimSlots));
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     h->fast_ok = true;
+    h->fast_steps = 0;
+    h->fast_calibrated = false;
     sp.n_any = n_any;
     sp.identity_any = identity ? 1 : 0;
     // deposit plan for scattered 'any' nodes: runs of consecutive nodes inside one 32-bit state word
@@ -472,7 +476,9 @@ namespace {
 constexpr uint64_t kFastMinProblems = 8192;     // below this the general kernel alone is used
 constexpr uint64_t kDiscoverySample = 65536;    // problems (sampled over the range) run through the detector when nothing is cached yet
 constexpr uint64_t kLeanTile = 1ull << 28;      // problems per lean-kernel launch (straggler list: 4 B each)
-constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps without a cached cycle state)
+constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps without a cached cycle state), first guess
+constexpr uint32_t kFastStepsMax = 3072;
+constexpr uint64_t kProbeTile = 1ull << 22;     // lean tiles while the FAST length is being calibrated
 
 using MergedTable = std::map<std::vector<uint32_t>, bsx_attr_rec, KeyLess>;
 
@@ -572,7 +578,8 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // cycles depend on the fixed nodes: with fixed-node variations they differ per problem
     P.cc.enabled = (h->cache_enabled && h->sp.n_fv == 0) ? 1u : 0u;
     P.cc.lds_slots = h->cache_lds_slots;
-    P.fast_steps = kFastSteps;
+    if (!h->fast_steps) h->fast_steps = kFastSteps;
+    P.fast_steps = h->fast_steps;
     if (const char* sl = std::getenv("BSX_SERVICE_LANES")) P.pad = (uint32_t)std::atoi(sl);
 
     MergedTable merged;
@@ -622,19 +629,23 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     }
     // Lean kernel over tiles; what it cannot resolve (attractors not cached yet, long transients) goes
     // through the detector right after each tile, which also teaches the cache for the next tile.
+    // The first tiles of a space are small probes: if most of their stragglers did end on a cached
+    // cycle state (just later than the FAST length), the FAST length is quadrupled for what follows.
     while (use_fast && h->fast_ok && done < count) {
-        const uint64_t tile = std::min<uint64_t>(count - done, kLeanTile);
+        const uint64_t tile = std::min<uint64_t>(count - done, h->fast_calibrated ? kLeanTile : kProbeTile);
         DevBuf<uint32_t>& d_strag = h->d_strag;
         if (d_strag.n < tile) HIPCHK(h, d_strag.alloc(tile));
         AttractParams Q = P;
         advance_first(Q.sp, first, done);
         Q.count = tile;
+        Q.fast_steps = h->fast_steps;
         Q.per_problem = per_problem ? d_pp.p + done : nullptr;
         Q.stragglers = d_strag.p;
         Q.stragglers_cap = tile;
         AttractRun r;
         if (int rc = launch_attract_pass(h, Q, true, d_log, &merged, r)) return rc;
         account(r);
+        uint64_t late = 0;
         if (r.ctr.n_stragglers) {
             AttractParams S = Q;
             S.count = r.ctr.n_stragglers;
@@ -643,9 +654,16 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             AttractRun rs;
             if (int rc = launch_attract_pass(h, S, false, d_log, &merged, rs)) return rc;
             account(rs);
+            late = rs.ctr.n_cache_resolved;
         }
         done += tile;
-        if (r.ctr.n_stragglers > tile / 2) h->fast_ok = false;    // the cache does not cover this space
+        const bool many = r.ctr.n_stragglers > tile / 32;
+        if (many && 2 * late >= r.ctr.n_stragglers && h->fast_steps < kFastStepsMax) {
+            h->fast_steps = std::min(kFastStepsMax, h->fast_steps * 4);     // long transients: give FAST more steps
+        } else {
+            if (tile >= kFastMinProblems) h->fast_calibrated = true;
+            if (r.ctr.n_stragglers > tile / 2) h->fast_ok = false;          // the cache does not cover this space
+        }
     }
     if (done < count) {
         AttractParams Q = P;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
     acc_t csl = 0, csl2 = 0;
 
     acc_t steps_ref = 0, steps_exec = 0;       // steps_ref: found problems only; the others add max_t each
-    uint32_t n_none = 0, n_capfail = 0, limit_hits = 0;
+    uint32_t n_none = 0, n_capfail = 0, limit_hits = 0, n_cached = 0;
 
 #ifdef BSX_DIAG
     unsigned long long dbg_iters = 0, dbg_service = 0;
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
                 n_capfail += found ? 0u : 1u;
                 const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
                 want_pub = found && pub && use_cache && lam <= kCycleCacheMaxLen;
+                n_cached += (found && !pub) ? 1u : 0u;              // ended on a cached cycle state
                 if (P.per_problem) {
                     ProblemRec32 r;
 #pragma unroll
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps_exec, lane);
     wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, lane);
     wave_atomic_add(&P.ctr->step_limit_hits, limit_hits, lane);
+    wave_atomic_add(&P.ctr->n_cache_resolved, (unsigned long long)n_cached, lane);
 }
 
 template <int NW, int K>

@@ -83,6 +83,7 @@ struct Counters {               // zeroed before every launch
     unsigned int log_overflow;
     unsigned int step_limit_hits;
     unsigned long long n_stragglers;    // fast kernel: problems handed to the general kernel
+    unsigned long long n_cache_resolved;// general kernel: problems that ended on a cached cycle state
     unsigned int straggler_overflow;
     unsigned int pad;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
