@@ -506,7 +506,11 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec
     HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
-    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu wave-iterations (%llu service rounds), chain walks %u, stragglers %llu, lane utilisation %.3f, %.3f ms, cycles/iter: head+service %.1f step %.1f; %llu waves, mean lifetime %.0f ticks = %.2f GHz if they live the whole kernel (prologue %.0f, epilogue %.0f)\n", fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec, (unsigned long long)run.ctr.wave_iters, (unsigned long long)run.ctr.service_rounds, run.ctr.pad, (unsigned long long)run.ctr.n_stragglers, run.ctr.wave_iters ? (double)run.ctr.steps_exec / (64.0 * (double)(run.ctr.wave_iters - run.ctr.service_rounds)) : 0.0, run.ms, run.ctr.wave_iters ? (double)run.ctr.cycles_service / (double)run.ctr.wave_iters : 0.0, run.ctr.wave_iters ? (double)run.ctr.cycles_step / (double)run.ctr.wave_iters : 0.0, (unsigned long long)run.ctr.n_waves, run.ctr.n_waves ? (double)run.ctr.cycles_wave / (double)run.ctr.n_waves : 0.0, run.ctr.n_waves ? (double)run.ctr.cycles_wave / (double)run.ctr.n_waves / (run.ms * 1e6) : 0.0, run.ctr.n_waves ? (double)run.ctr.cycles_prologue / (double)run.ctr.n_waves : 0.0, run.ctr.n_waves ? (double)run.ctr.cycles_epilogue / (double)run.ctr.n_waves : 0.0);
+    if (std::getenv("BSX_DEBUG"))
+        std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu stragglers, %.3f ms (BSX_DIAG build: %llu wave iterations, %llu service rounds)\n",
+                     fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
+                     (unsigned long long)run.ctr.n_stragglers, run.ms, (unsigned long long)run.ctr.wave_iters,
+                     (unsigned long long)run.ctr.service_rounds);
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
     if (!merged) return BSX_OK;
     const uint64_t n_log = run.ctr.log_cursor;

@@ -88,12 +88,6 @@ struct Counters {               // zeroed before every launch
     unsigned int pad;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic
-    unsigned long long cycles_service;  // diagnostic (BSX_DIAG): shader cycles summed over waves
-    unsigned long long cycles_step;
-    unsigned long long cycles_wave;     // diagnostic: wave lifetimes
-    unsigned long long n_waves;
-    unsigned long long cycles_prologue;
-    unsigned long long cycles_epilogue;
 };
 
 // Cache of known cycle states (DESIGN.md "cycle-state cache").  A trajectory enters its attractor at
