@@ -18,18 +18,18 @@
 #include "bsx_device.h"
 
 namespace bsx {
-hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
-hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
-hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
-hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
+hipError_t launch_attract(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
+hipError_t launch_attract_fast(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
+hipError_t launch_target(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P);
+hipError_t launch_simulate(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P);
 hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P);
 hipError_t launch_simulate_sliced64(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P);
 hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
-hipError_t configure_attract(int nw, int k, bool lds, size_t shmem);
-hipError_t configure_attract_fast(int nw, int k, bool lds, size_t shmem, int* blocks_per_cu);
-hipError_t configure_target(int nw, int k, bool lds, size_t shmem);
-hipError_t configure_simulate(int nw, int k, bool lds, size_t shmem);
+hipError_t configure_attract(int nw, int k, int lut_mode, size_t shmem);
+hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
+hipError_t configure_target(int nw, int k, int lut_mode, size_t shmem);
+hipError_t configure_simulate(int nw, int k, int lut_mode, size_t shmem);
 }  // namespace bsx
 
 using namespace bsx;
@@ -71,7 +71,7 @@ struct bsx_engine {
     bool have_net = false;
     uint32_t n_nodes = 0, w64 = 0;
     DevNet net{};
-    bool lut_in_lds = false;
+    int lut_mode = 0;           // kLutGlobal / kLutLdsByte / kLutLdsNibble (bsx_kernels_common.h)
     size_t shmem = 0;           // masks (+ LUT) : target / simulate kernels
     size_t shmem_attract = 0;   // + LDS mirror of the cycle-state cache
 
@@ -239,9 +239,31 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
         else k_mux = std::max(k_mux, k);
     }
 
-    const uint32_t n_chunks = nw * 4;       // zero entries for the bytes beyond n keep the gather branch-free
+    // LDS budget: masks (+pad) [+ LUT] [+ cycle-cache mirror].  The LUT stays in LDS while a workgroup
+    // fits in 144 KiB: one entry per state byte if that fits, else (beyond 64 nodes) one entry per 4 state
+    // bits -- a 16x smaller table for twice the lookups -- else the byte table is read through L2.
+    const size_t mask_bytes = (((size_t)(1u << k_mux) * nw + 3) & ~size_t(3)) * 4;
+    const size_t cache_stride = ((2 * nw + 2 + 3) & ~3u) * 4;
+    uint32_t slots = 1;
+    size_t cache_lds = kCycleCacheLdsBytes;
+    if (const char* kb = std::getenv("BSX_CACHE_LDS_KB")) cache_lds = std::max<size_t>(1, (size_t)std::atoi(kb)) * 1024;   // tuning knob
+    while ((size_t)slots * 2 * cache_stride <= cache_lds) slots *= 2;
+    h->cache_lds_slots = slots;
+    const size_t cache_bytes = (size_t)slots * cache_stride + 16 + 16      // + header + alignment
+                               + lean_acc_bytes(nw);                         // + lean kernel's per-attractor tables
+    const size_t entry_bytes = (size_t)k_mux * nw * 4;
+    const size_t fixed_bytes = mask_bytes + cache_bytes + 64;
+    int lut_mode = 0;                                                       // kLutGlobal
+    if (fixed_bytes + (size_t)nw * 4 * 256 * entry_bytes <= 144 * 1024) lut_mode = 1;                  // kLutLdsByte
+    else if (nw >= 4 && fixed_bytes + (size_t)nw * 8 * 16 * entry_bytes <= 144 * 1024) lut_mode = 2;   // kLutLdsNibble
+    if (const char* m = std::getenv("BSX_LUT_MODE")) {                      // test knob: force a smaller-footprint mode
+        const int want = std::atoi(m);
+        if (want == 0 || (want == 2 && nw >= 4 && fixed_bytes + (size_t)nw * 8 * 16 * entry_bytes <= 144 * 1024)) lut_mode = want;
+    }
+    const uint32_t chunk_bits = lut_mode == 2 ? 4 : 8, chunk_entries = 1u << chunk_bits;
+    const uint32_t n_chunks = nw * 32 / chunk_bits;     // zero entries for the chunks beyond n keep the gather branch-free
     std::vector<uint32_t> masks((size_t)(1u << k_mux) * nw, 0);
-    std::vector<uint32_t> lut((size_t)n_chunks * 256 * k_mux * nw, 0);
+    std::vector<uint32_t> lut((size_t)n_chunks * chunk_entries * k_mux * nw, 0);
     for (uint32_t i = 0; i < n_nodes; ++i) {
         const uint32_t k = pred_offsets[i + 1] - pred_offsets[i];
         if (k > (uint32_t)kMaxMuxK) continue;
@@ -250,10 +272,10 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
             if ((tt >> (idx & ((1u << k) - 1))) & 1ull) masks[(size_t)idx * nw + (i >> 5)] |= 1u << (i & 31);
         for (uint32_t j = 0; j < k; ++j) {
             const uint32_t p = pred_idx[pred_offsets[i] + j];
-            const uint32_t chunk = p >> 3, bit = p & 7;
-            for (uint32_t v = 0; v < 256; ++v)
+            const uint32_t chunk = p / chunk_bits, bit = p % chunk_bits;
+            for (uint32_t v = 0; v < chunk_entries; ++v)
                 if ((v >> bit) & 1u)
-                    lut[(((size_t)chunk * 256 + v) * k_mux + j) * nw + (i >> 5)] |= 1u << (i & 31);
+                    lut[(((size_t)chunk * chunk_entries + v) * k_mux + j) * nw + (i >> 5)] |= 1u << (i & 31);
         }
     }
     std::vector<uint32_t> wdesc, wpreds, wtt;
@@ -292,26 +314,15 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     h->net.wide_preds = h->d_wide_preds.p;
     h->net.wide_tt = h->d_wide_tt.p;
 
-    // LDS budget: masks (+pad) [+ LUT] [+ cycle-cache mirror].  Keep the LUT in LDS while a
-    // workgroup fits in 144 KiB.
-    const size_t mask_bytes = (((size_t)(1u << k_mux) * nw + 3) & ~size_t(3)) * 4;
     const size_t lut_bytes = lut.size() * 4;
-    const size_t cache_stride = ((2 * nw + 2 + 3) & ~3u) * 4;
-    uint32_t slots = 1;
-    size_t cache_lds = kCycleCacheLdsBytes;
-    if (const char* kb = std::getenv("BSX_CACHE_LDS_KB")) cache_lds = std::max<size_t>(1, (size_t)std::atoi(kb)) * 1024;   // tuning knob
-    while ((size_t)slots * 2 * cache_stride <= cache_lds) slots *= 2;
-    h->cache_lds_slots = slots;
-    const size_t cache_bytes = (size_t)slots * cache_stride + 16 + 16      // + header + alignment
-                               + lean_acc_bytes(nw);                         // + lean kernel's per-attractor tables
-    h->lut_in_lds = mask_bytes + lut_bytes + cache_bytes + 64 <= 144 * 1024;
-    h->shmem = mask_bytes + (h->lut_in_lds ? lut_bytes : 0) + 64;
+    h->lut_mode = lut_mode;
+    h->shmem = mask_bytes + (lut_mode ? lut_bytes : 0) + 64;
     h->shmem_attract = h->shmem + cache_bytes;
-    HIPCHK(h, configure_attract((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract));
-    HIPCHK(h, configure_attract_fast((int)nw, (int)k_mux, h->lut_in_lds, h->shmem_attract, &h->lean_blocks_per_cu));
-    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] network: nw %u k_mux %u lut_in_lds %d shmem %zu attract shmem %zu lean blocks/CU %d\n", nw, k_mux, (int)h->lut_in_lds, h->shmem, h->shmem_attract, h->lean_blocks_per_cu);
-    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
-    HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_in_lds, h->shmem));
+    HIPCHK(h, configure_attract((int)nw, (int)k_mux, h->lut_mode, h->shmem_attract));
+    HIPCHK(h, configure_attract_fast((int)nw, (int)k_mux, h->lut_mode, h->shmem_attract, &h->lean_blocks_per_cu));
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] network: nw %u k_mux %u lut mode %d (0 L2 bytes, 1 LDS bytes, 2 LDS nibbles) shmem %zu attract shmem %zu lean blocks/CU %d\n", nw, k_mux, (int)h->lut_mode, h->shmem, h->shmem_attract, h->lean_blocks_per_cu);
+    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_mode, h->shmem));
+    HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_mode, h->shmem));
     h->have_net = true;
     return BSX_OK;
 }
@@ -500,8 +511,8 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec
     P.log_cap = log_cap;
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (fast) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem_attract, h->stream, P));
-    else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem_attract, h->stream, P));
+    if (fast) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, h->shmem_attract, h->stream, P));
+    else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, h->shmem_attract, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -742,7 +753,7 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
 
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, L.grid, h->shmem, h->stream, P));
+    HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, h->shmem, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     Counters ctr{};
     HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
@@ -824,7 +835,7 @@ static int run_sim_common(bsx_handle h, const bsx_index* first, uint64_t count, 
     const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 4, (count + kBlock - 1) / kBlock));
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_simulate((int)h->net.nw, (int)h->net.k_mux, h->lut_in_lds, dim3((uint32_t)blocks), h->shmem, h->stream, P));
+    HIPCHK(h, launch_simulate((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     Counters ctr{};
     HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));

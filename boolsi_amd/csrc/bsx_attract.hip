@@ -15,11 +15,11 @@ namespace bsx {
 // Minimum waves per SIMD requested from the register allocator (a 512-thread workgroup is 2 per SIMD).
 constexpr int attract_min_waves(int nw) { return nw <= 2 ? 4 : 2; }
 
-template <int NW, int K, bool LDS_LUT>
+template <int NW, int K, int LM>
 __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool has_warmup = (P.sp.tp_origin | P.sp.n_pv) != 0;                      // wave-uniform
     const bool simple_space = bsx::simple_space(P.sp);
@@ -305,24 +305,27 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
 }
 
 template <int NW, int K>
-static hipError_t launch_attract_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    if (lds) hipLaunchKernelGGL((k_attract<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_attract<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
-    return hipGetLastError();
+static hipError_t launch_attract_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_attract, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    void* args[] = {const_cast<AttractParams*>(&P)};
+    return hipLaunchKernel(fn, grid, dim3(kBlock), args, shmem, st);
 }
 template <int NW, int K>
-static hipError_t configure_attract_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
-    const int bytes = (int)shmem;
-    if (lds) return hipFuncSetAttribute((const void*)k_attract<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return hipFuncSetAttribute((const void*)k_attract<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+static hipError_t configure_attract_nk(int lut_mode, dim3, size_t shmem, hipStream_t, const int&) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_attract, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 }
 
-hipError_t launch_attract(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+hipError_t launch_attract(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
     BSX_DISPATCH(launch_attract_nk)
 }
 // Allow the instantiation used by a network to take `shmem` bytes of dynamic LDS (above 64 KiB this
 // must be requested explicitly).
-hipError_t configure_attract(int nw, int k, bool lds, size_t shmem) {
+hipError_t configure_attract(int nw, int k, int lut_mode, size_t shmem) {
     const dim3 grid(1);
     const hipStream_t st = nullptr;
     const int P = 0;

@@ -84,13 +84,20 @@ __device__ __forceinline__ void put_bit(uint32_t (&s)[NW], uint32_t node, uint32
 
 // ------------------------------------------------------------------------------------------------
 // Network tables as seen by a workgroup: LUT and masks either in LDS or (large networks) in HBM/L2.
-template <int NW, int K, bool LDS = false>
+// LUT modes: where the gather LUT lives and how the state is cut into lookups.
+constexpr int kLutGlobal = 0;       // one entry per state byte, read through L2 (the table does not fit LDS)
+constexpr int kLutLdsByte = 1;      // one entry per state byte, in LDS
+constexpr int kLutLdsNibble = 2;    // one entry per 4 state bits, in LDS: 16x smaller table, twice the lookups
+                                    // (networks beyond 64 nodes whose byte table would not fit)
+
+template <int NW, int K, int LM = kLutGlobal>
 struct NetView {
+    static constexpr bool LDS = LM != kLutGlobal;
     static constexpr bool kMasksInRegs = (K <= 3);
     // LDS = true: the gather LUT sits in LDS right behind the masks, and the kernel's dynamic LDS starts
     // at LDS address 0 (checked by stage_network), so an entry's address is a compile-time constant plus
     // the scaled byte -- no base-pointer add per lookup.
-    static constexpr uint32_t kLutLdsByte = ((((1u << K) * NW) + 3u) & ~3u) * 4u;
+    static constexpr uint32_t kLutLdsAddr = ((((1u << K) * NW) + 3u) & ~3u) * 4u;
     const uint32_t* lut;     // LDS or global
     const uint32_t* masks;   // LDS (used when the 2^K * NW mask words do not fit the register budget)
     uint32_t mreg[kMasksInRegs ? (1 << K) * NW : 1];
@@ -168,8 +175,8 @@ __device__ __forceinline__ void load_entry_lds(uint32_t byte_addr, uint32_t (&ds
 }
 
 // One synchronous update of all nodes (model.py:16-28) + fixed nodes as constants (model.py:31-49).
-template <int NW, int K, bool LDS>
-__device__ __forceinline__ void net_step(const NetView<NW, K, LDS>& nv, const uint32_t (&s)[NW],
+template <int NW, int K, int LM>
+__device__ __forceinline__ void net_step(const NetView<NW, K, LM>& nv, const uint32_t (&s)[NW],
                                          const uint32_t (&fm)[NW], const uint32_t (&fv)[NW],
                                          uint32_t (&out)[NW]) {
     uint32_t g[K][NW];
@@ -178,32 +185,39 @@ __device__ __forceinline__ void net_step(const NetView<NW, K, LDS>& nv, const ui
 #pragma unroll
         for (int w = 0; w < NW; ++w) g[j][w] = 0;
 
-    // gather: one LUT entry per 8 state bits.  All NW*4 lookups are issued unconditionally (the LUT
+    // gather: one LUT entry per 8 (or 4) state bits.  All lookups are issued unconditionally (the LUT
     // is zero-padded to whole 32-bit words of state) so the LDS reads overlap instead of each
     // waiting behind a branch.
     // Lookups are issued in batches sized to keep the in-flight entries within ~64 registers.
+    constexpr bool LDS = LM != kLutGlobal;
     constexpr int kEntry = K * NW;
-    constexpr int kBatch = (64 / kEntry) < 1 ? 1 : ((64 / kEntry) > NW * 4 ? NW * 4 : (64 / kEntry));
+    constexpr int kLookups = (LM == kLutLdsNibble) ? NW * 8 : NW * 4;
+    constexpr int kBatch = (64 / kEntry) < 1 ? 1 : ((64 / kEntry) > kLookups ? kLookups : (64 / kEntry));
 #pragma unroll
-    for (int c0 = 0; c0 < NW * 4; c0 += kBatch) {
+    for (int c0 = 0; c0 < kLookups; c0 += kBatch) {
         uint32_t e[kBatch][kEntry];
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
             const int ch = c0 + b;
-            if (ch < NW * 4) {
-                // byte offset of the entry within its chunk's table: (byte ch of the state) * entry size,
-                // one SDWA multiply instead of extract + scale
-                const uint32_t off = byte_times(s[ch >> 2], (uint32_t)(kEntry * 4), ch & 3);
-                if constexpr (LDS)
-                    load_entry_lds<kEntry>(NetView<NW, K, LDS>::kLutLdsByte + (uint32_t)(ch << 8) * kEntry * 4u + off, e[b]);
-                else
-                    load_entry<kEntry>(reinterpret_cast<const uint32_t*>(
-                                           reinterpret_cast<const char*>(nv.lut + (uint32_t)(ch << 8) * kEntry) + off), e[b]);
+            if (ch < kLookups) {
+                if constexpr (LM == kLutLdsNibble) {
+                    const uint32_t off = ((s[ch >> 3] >> ((ch & 7) * 4)) & 15u) * (uint32_t)(kEntry * 4);
+                    load_entry_lds<kEntry>(NetView<NW, K, LM>::kLutLdsAddr + (uint32_t)(ch << 4) * kEntry * 4u + off, e[b]);
+                } else {
+                    // byte offset of the entry within its chunk's table: (byte ch of the state) * entry size,
+                    // one SDWA multiply instead of extract + scale
+                    const uint32_t off = byte_times(s[ch >> 2], (uint32_t)(kEntry * 4), ch & 3);
+                    if constexpr (LDS)
+                        load_entry_lds<kEntry>(NetView<NW, K, LM>::kLutLdsAddr + (uint32_t)(ch << 8) * kEntry * 4u + off, e[b]);
+                    else
+                        load_entry<kEntry>(reinterpret_cast<const uint32_t*>(
+                                               reinterpret_cast<const char*>(nv.lut + (uint32_t)(ch << 8) * kEntry) + off), e[b]);
+                }
             }
         }
 #pragma unroll
         for (int b = 0; b < kBatch; ++b)
-            if (c0 + b < NW * 4) {
+            if (c0 + b < kLookups) {
 #pragma unroll
                 for (int j = 0; j < K; ++j)
 #pragma unroll
@@ -217,7 +231,7 @@ __device__ __forceinline__ void net_step(const NetView<NW, K, LDS>& nv, const ui
     for (int i = 0; i < (1 << (K - 1)); ++i)
 #pragma unroll
         for (int w = 0; w < NW; ++w)
-            r[i][w] = NetView<NW, K, LDS>::kMasksInRegs
+            r[i][w] = NetView<NW, K, LM>::kMasksInRegs
                           ? bfi(g[0][w], nv.mreg[(2 * i + 1) * NW + w], nv.mreg[(2 * i) * NW + w])
                           : bfi(g[0][w], nv.masks[(2 * i + 1) * NW + w], nv.masks[(2 * i) * NW + w]);
 #pragma unroll
@@ -356,9 +370,10 @@ __device__ __forceinline__ void apply_perturbations(const DevSpace& sp, uint32_t
 
 // ------------------------------------------------------------------------------------------------
 // Workgroup prologue: stage LUT + masks into LDS.
-template <int NW, int K, bool LDS_LUT>
-__device__ __forceinline__ NetView<NW, K, LDS_LUT> stage_network(const DevNet& net, uint32_t* smem, uint32_t*& smem_free) {
-    NetView<NW, K, LDS_LUT> nv;
+template <int NW, int K, int LM>
+__device__ __forceinline__ NetView<NW, K, LM> stage_network(const DevNet& net, uint32_t* smem, uint32_t*& smem_free) {
+    constexpr bool LDS_LUT = LM != kLutGlobal;
+    NetView<NW, K, LM> nv;
     if constexpr (LDS_LUT) {
         // net_step addresses the LUT by absolute LDS byte offsets: the dynamic LDS block must start at 0
         // (true for kernels without static LDS; anything else is a build error, so stop loudly)
@@ -382,7 +397,7 @@ __device__ __forceinline__ NetView<NW, K, LDS_LUT> stage_network(const DevNet& n
     }
     __syncthreads();
     nv.masks = smasks;
-    if constexpr (NetView<NW, K, LDS_LUT>::kMasksInRegs) {
+    if constexpr (NetView<NW, K, LM>::kMasksInRegs) {
 #pragma unroll
         for (int i = 0; i < (1 << K) * NW; ++i) nv.mreg[i] = smasks[i];
     } else {
@@ -620,8 +635,8 @@ __device__ __forceinline__ void cache_insert_lds(uint32_t* lc, uint32_t mask, co
 
 // Thread 0: take the attractors published since `seen` (by any workgroup) from the HBM journal,
 // regenerate their cycles from the key and make each cycle visible in the LDS mirror at once.
-template <int NW, int K, bool LDS>
-__device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<NW, K, LDS>& nv,
+template <int NW, int K, int LM>
+__device__ __forceinline__ void cache_pull(const CycleCache& cc, const NetView<NW, K, LM>& nv,
                                            const uint32_t (&fm)[NW], const uint32_t (&fv)[NW], uint32_t* lc,
                                            uint32_t& seen, uint32_t& n_states, uint32_t& n_attr,
                                            uint32_t max_attr = 0xFFFFFFFFu) {
@@ -705,15 +720,24 @@ __device__ __forceinline__ bool simple_space(const DevSpace& sp) {
 
 }  // namespace bsx
 
+// Address of the instantiation of KERNEL for a LUT mode (nibble tables are only built beyond 64 nodes).
+#define BSX_KERNEL_FOR_MODE(KERNEL, NWV, KV, MODE, OUT)                                             \
+    do {                                                                                            \
+        OUT = nullptr;                                                                              \
+        if ((MODE) == kLutLdsByte) OUT = (const void*)KERNEL<NWV, KV, kLutLdsByte>;                 \
+        else if ((MODE) == kLutGlobal) OUT = (const void*)KERNEL<NWV, KV, kLutGlobal>;              \
+        else if constexpr ((NWV) >= 4) { if ((MODE) == kLutLdsNibble) OUT = (const void*)KERNEL<NWV, KV, kLutLdsNibble>; } \
+    } while (0)
+
 // Launch dispatch over (NW, K): NW in {1,2,4,8}; K in 1..6.
 #define BSX_DISPATCH_K(FN, NWV)                                                         \
     switch (k) {                                                                        \
-        case 1: return FN<NWV, 1>(lds, grid, shmem, st, P);                             \
-        case 2: return FN<NWV, 2>(lds, grid, shmem, st, P);                             \
-        case 3: return FN<NWV, 3>(lds, grid, shmem, st, P);                             \
-        case 4: return FN<NWV, 4>(lds, grid, shmem, st, P);                             \
-        case 5: return FN<NWV, 5>(lds, grid, shmem, st, P);                             \
-        case 6: return FN<NWV, 6>(lds, grid, shmem, st, P);                             \
+        case 1: return FN<NWV, 1>(lut_mode, grid, shmem, st, P);                             \
+        case 2: return FN<NWV, 2>(lut_mode, grid, shmem, st, P);                             \
+        case 3: return FN<NWV, 3>(lut_mode, grid, shmem, st, P);                             \
+        case 4: return FN<NWV, 4>(lut_mode, grid, shmem, st, P);                             \
+        case 5: return FN<NWV, 5>(lut_mode, grid, shmem, st, P);                             \
+        case 6: return FN<NWV, 6>(lut_mode, grid, shmem, st, P);                             \
         default: return hipErrorInvalidValue;                                           \
     }
 

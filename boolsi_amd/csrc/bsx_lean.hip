@@ -35,11 +35,11 @@ constexpr int lean_min_waves(int nw) { return nw <= 2 ? 6 : nw == 4 ? 4 : 2; }
 constexpr uint32_t kResLost = 0x7FFFFFFEu;
 constexpr uint32_t kResIdle = 0x7FFFFFFFu;
 
-template <int NW, int K, bool LDS_LUT>
+template <int NW, int K, int LM>
 __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
     const bool has_warmup = tp != 0;
@@ -270,26 +270,28 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
 }
 
 template <int NW, int K>
-static hipError_t launch_lean_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    if (lds) hipLaunchKernelGGL((k_attract_lean<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_attract_lean<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
-    return hipGetLastError();
+static hipError_t launch_lean_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_attract_lean, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    void* args[] = {const_cast<AttractParams*>(&P)};
+    return hipLaunchKernel(fn, grid, dim3(kBlock), args, shmem, st);
 }
 template <int NW, int K>
-static hipError_t configure_lean_nk(bool lds, dim3, size_t shmem, hipStream_t, int& blocks_per_cu) {
-    const int bytes = (int)shmem;
-    const void* fn = lds ? (const void*)k_attract_lean<NW, K, true> : (const void*)k_attract_lean<NW, K, false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+static hipError_t configure_lean_nk(int lut_mode, dim3, size_t shmem, hipStream_t, int& blocks_per_cu) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_attract_lean, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    if (lds) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_attract_lean<NW, K, true>, kBlock, shmem);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_attract_lean<NW, K, false>, kBlock, shmem);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, shmem);
 }
 
-hipError_t launch_attract_fast(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+hipError_t launch_attract_fast(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
     BSX_DISPATCH(launch_lean_nk)
 }
 // Also reports how many workgroups of the kernel fit on one CU (registers + LDS), which sizes its grid.
-hipError_t configure_attract_fast(int nw, int k, bool lds, size_t shmem, int* blocks_per_cu) {
+hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu) {
     const dim3 grid(1);
     const hipStream_t st = nullptr;
     int& P = *blocks_per_cu;

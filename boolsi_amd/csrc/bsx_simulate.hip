@@ -5,11 +5,11 @@ namespace bsx {
 
 // ------------------------------------------------------------------------------------------------
 // simulate: s(0..T) by plain stepping (simulate.py:97-131 == S11); sinks: trajectory, final state, digest.
-template <int NW, int K, bool LDS_LUT>
+template <int NW, int K, int LM>
 __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t steps = 0;
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < P.count; qi += stride) {
@@ -54,21 +54,27 @@ __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
 
 
 template <int NW, int K>
-static hipError_t launch_simulate_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
-    if (lds) hipLaunchKernelGGL((k_simulate<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_simulate<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
-    return hipGetLastError();
+static hipError_t launch_simulate_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_simulate, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    void* args[] = {const_cast<SimParams*>(&P)};
+    return hipLaunchKernel(fn, grid, dim3(kBlock), args, shmem, st);
 }
 template <int NW, int K>
-static hipError_t configure_simulate_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
-    return lds ? hipFuncSetAttribute((const void*)k_simulate<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
-               : hipFuncSetAttribute((const void*)k_simulate<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+static hipError_t configure_simulate_nk(int lut_mode, dim3, size_t shmem, hipStream_t, const int&) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_simulate, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 }
 
-hipError_t launch_simulate(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
+hipError_t launch_simulate(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const SimParams& P) {
     BSX_DISPATCH(launch_simulate_nk)
 }
-hipError_t configure_simulate(int nw, int k, bool lds, size_t shmem) {
+// Allow the instantiation used by a network to take `shmem` bytes of dynamic LDS (above 64 KiB this
+// must be requested explicitly).
+hipError_t configure_simulate(int nw, int k, int lut_mode, size_t shmem) {
     const dim3 grid(1);
     const hipStream_t st = nullptr;
     const int P = 0;

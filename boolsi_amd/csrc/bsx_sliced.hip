@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
 }
 
 template <int NW, int K>
-static hipError_t launch_sliced_nk(bool, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
+static hipError_t launch_sliced_nk(int, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
     hipError_t e = hipFuncSetAttribute((const void*)k_simulate_sliced<NW, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_simulate_sliced<NW, K>), grid, dim3(64 * kSlicedWaves), shmem, st, P);
@@ -316,7 +316,7 @@ static hipError_t launch_sliced64_nk(dim3 grid, size_t shmem, hipStream_t st, co
 }
 
 hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
-    const bool lds = true;
+    const int lut_mode = 0;        // unused by this kernel (no gather LUT)
     BSX_DISPATCH(launch_sliced_nk)
 }
 

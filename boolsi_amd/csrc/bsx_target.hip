@@ -17,11 +17,11 @@ __device__ __forceinline__ bool target_hit(const uint32_t (&s)[NW], const uint32
 // Output: t_hit[p] for every problem (kNotReached if none); k_compact_* turn it into the hit list.
 constexpr uint32_t kNotReached = 0xFFFFFFFFu;
 
-template <int NW, int K, bool LDS_LUT>
+template <int NW, int K, int LM>
 __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const TargetParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
-    const NetView<NW, K, LDS_LUT> nv = stage_network<NW, K, LDS_LUT>(P.net, smem, smem_free);
+    const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool simple_space = bsx::simple_space(P.sp);
 
@@ -149,26 +149,33 @@ __global__ __launch_bounds__(256) void k_compact_write(const uint32_t* t_hit, ui
 
 
 template <int NW, int K>
-static hipError_t launch_target_nk(bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
-    if (lds) hipLaunchKernelGGL((k_target<NW, K, true>), grid, dim3(kBlock), shmem, st, P);
-    else hipLaunchKernelGGL((k_target<NW, K, false>), grid, dim3(kBlock), shmem, st, P);
-    return hipGetLastError();
+static hipError_t launch_target_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_target, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    void* args[] = {const_cast<TargetParams*>(&P)};
+    return hipLaunchKernel(fn, grid, dim3(kBlock), args, shmem, st);
 }
 template <int NW, int K>
-static hipError_t configure_target_nk(bool lds, dim3, size_t shmem, hipStream_t, const int&) {
-    return lds ? hipFuncSetAttribute((const void*)k_target<NW, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
-               : hipFuncSetAttribute((const void*)k_target<NW, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+static hipError_t configure_target_nk(int lut_mode, dim3, size_t shmem, hipStream_t, const int&) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_target, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
 }
 
-hipError_t launch_target(int nw, int k, bool lds, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
+hipError_t launch_target(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const TargetParams& P) {
     BSX_DISPATCH(launch_target_nk)
 }
-hipError_t configure_target(int nw, int k, bool lds, size_t shmem) {
+// Allow the instantiation used by a network to take `shmem` bytes of dynamic LDS (above 64 KiB this
+// must be requested explicitly).
+hipError_t configure_target(int nw, int k, int lut_mode, size_t shmem) {
     const dim3 grid(1);
     const hipStream_t st = nullptr;
     const int P = 0;
     BSX_DISPATCH(configure_target_nk)
 }
+
 hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_counts, const uint64_t* seg_base,
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st) {
     const uint32_t blocks = (uint32_t)((count + kCompactSegment - 1) / kCompactSegment);

@@ -349,6 +349,29 @@ def test_largest_network_and_rule_width(eng):
     _same_attract(eng, orc, 0, 1 << 13, 5000)
 
 
+@pytest.mark.parametrize('lut_mode', ['0', '1', '2'])
+def test_lut_modes_agree_with_the_oracle(eng, lut_mode):
+    """The gather LUT read through L2 (0), from LDS per state byte (1) and from LDS per 4 state bits (2)."""
+    bits = synth.seeded_bits(100, 1003)
+    text = synth.network_yaml(100, 2, 1002, initial={i: str(bits[i]) for i in range(36, 100)})
+    os.environ['BSX_LUT_MODE'] = lut_mode
+    try:
+        cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 3000)
+    finally:
+        os.environ.pop('BSX_LUT_MODE')
+    _same_attract(eng, orc, 0, 1 << 14, 3000)               # discovery + lean kernel
+    _same_attract(eng, orc, (1 << 35) + 99, 20000, 3000)
+    _same_attract(eng, orc, 5, 3000, 40, 3)                 # general kernel only (below the lean threshold), caps
+    tm, tc = code_to_words(0b111 << 40, net.n_words), code_to_words(0b101 << 40, net.n_words)
+    hits, _ = eng.target(77, 1 << 13, 300, tm, tc)
+    ref, _ = orc.target(77, 1 << 13, 300, tm, tc, n_threads=8)
+    want = np.nonzero(ref['reached'])[0]
+    assert np.array_equal(hits['offset'], want) and np.array_equal(hits['t'], ref['t_stop'][want])
+    traj, fin, dig, _ = eng.simulate(123, 300, 50)
+    otraj, ofin, odig, _ = orc.simulate(123, 300, 50, n_threads=8)
+    assert np.array_equal(traj, otraj) and np.array_equal(fin, ofin) and np.array_equal(dig, odig)
+
+
 # ---------------------------------------------------------------------------------------------------
 # bit-sliced simulate kernel (final states of long fixed-length runs)
 
