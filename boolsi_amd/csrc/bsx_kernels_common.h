@@ -175,10 +175,11 @@ __device__ __forceinline__ void load_entry_lds(uint32_t byte_addr, uint32_t (&ds
 }
 
 // One synchronous update of all nodes (model.py:16-28) + fixed nodes as constants (model.py:31-49).
+// `has_fixed` (wave-uniform) = some node is fixed; without fixed nodes the final mask pass is skipped.
 template <int NW, int K, int LM>
 __device__ __forceinline__ void net_step(const NetView<NW, K, LM>& nv, const uint32_t (&s)[NW],
                                          const uint32_t (&fm)[NW], const uint32_t (&fv)[NW],
-                                         uint32_t (&out)[NW]) {
+                                         uint32_t (&out)[NW], bool has_fixed = true) {
     uint32_t g[K][NW];
 #pragma unroll
     for (int j = 0; j < K; ++j)
@@ -254,8 +255,10 @@ __device__ __forceinline__ void net_step(const NetView<NW, K, LM>& nv, const uin
         put_bit<NW>(out, node, bit);
     }
 
+    if (has_fixed) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) out[w] = (out[w] & ~fm[w]) | fv[w];
+        for (int w = 0; w < NW; ++w) out[w] = (out[w] & ~fm[w]) | fv[w];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,8 +59,10 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     uint32_t* keytab = lamtab + kAccs;
 
     uint32_t fm0[NW], fv0[NW];
+    uint32_t any_fixed = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; }
+    for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; any_fixed |= fm0[w]; }
+    const bool has_fixed = any_fixed != 0;                  // uniform
     for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
     for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
     __syncthreads();
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     unsigned long long extra_ref = 0, extra_exec = 0;
     uint32_t n_none = 0, n_capfail = 0;
     WaveQueue q{0, 0, true};
+    uint32_t since_service = 0;
 #ifdef BSX_DIAG
     unsigned long long dbg_iters = 0, dbg_service = 0;
 #endif
@@ -149,11 +152,15 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
 #ifdef BSX_DIAG
         ++dbg_iters;
 #endif
-        if ((work_left && n_free >= service_lanes) || !running) {
+        // a round is also forced every 32 iterations, so that lanes running past fast_steps are noticed
+        // even when no lane of the wave ever gets free
+        if ((work_left && n_free >= service_lanes) || !running || ++since_service >= 32u) {
+            since_service = 0;
 #ifdef BSX_DIAG
             ++dbg_service;
 #endif
             // ---- service round: record results, hand lost problems over, refill
+            if (res == 0 && t >= fast_steps) res = kResLost;    // no cached cycle state within fast_steps
             if (res != 0 && res != kResIdle) {
                 if (res == kResLost) {
                     const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
         //      are masked off: their LDS reads would only add bank conflicts.
         if (res == 0) {
             uint32_t nxt[NW];
-            net_step<NW, K>(nv, A, fm0, fv0, nxt);
+            net_step<NW, K>(nv, A, fm0, fv0, nxt, has_fixed);
             ++t;
             if (has_warmup) {
                 if (t <= 0) apply_perturbations<NW>(P.sp, (uint32_t)((int32_t)tp + t), 0ull, nxt);
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
             if (has_warmup) et = t >= 0 ? et : 0u;          // states before T_p do not count
 #pragma unroll
             for (int w = 0; w < NW; ++w) A[w] = nxt[w];
-            res = et ? et : (t >= fast_steps ? kResLost : 0u);
+            res = et;               // 0 = keep running; running too long is noticed in the service round
         }
     }
 
