@@ -646,6 +646,9 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // through the detector right after each tile, which also teaches the cache for the next tile.
     // The first tiles of a space are small probes: if most of their stragglers did end on a cached
     // cycle state (just later than the FAST length), the FAST length is quadrupled for what follows.
+    // BSX_MERGE=0: lean kernel without the sibling merge (A/B runs, tests)
+    const char* merge_env = std::getenv("BSX_MERGE");
+    const bool merge_lanes = !(merge_env && merge_env[0] == '0');
     while (use_fast && h->fast_ok && done < count) {
         const uint64_t tile = std::min<uint64_t>(count - done, h->fast_calibrated ? kLeanTile : kProbeTile);
         DevBuf<uint32_t>& d_strag = h->d_strag;
@@ -654,18 +657,51 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         advance_first(Q.sp, first, done);
         Q.count = tile;
         Q.fast_steps = h->fast_steps;
+        Q.merge = merge_lanes ? 1u : 0u;
         Q.per_problem = per_problem ? d_pp.p + done : nullptr;
         Q.stragglers = d_strag.p;
         Q.stragglers_cap = tile;
         AttractRun r;
-        if (int rc = launch_attract_pass(h, Q, true, d_log, &merged, r)) return rc;
+        MergedTable tile_table;         // folded into `merged` only if the pass is accepted
+        if (int rc = launch_attract_pass(h, Q, true, d_log, &tile_table, r)) return rc;
+        if (r.ctr.straggler_overflow) {
+            // more (group, mask) pairs than the list holds: the cache does not cover this space.  Drop the
+            // pass and give the rest of the range to the detector.
+            kernel_ms += r.ms; ++launches;
+            h->fast_ok = false;
+            break;
+        }
+        for (auto& kv : tile_table) {
+            auto it = merged.find(kv.first);
+            if (it == merged.end()) { merged.emplace(kv.first, kv.second); continue; }
+            bsx_attr_rec& a = it->second;
+            a.count += kv.second.count;
+            a.sum_l += kv.second.sum_l;
+            const uint64_t lo = a.sum_l2_lo + kv.second.sum_l2_lo;
+            a.sum_l2_hi += kv.second.sum_l2_hi + (lo < a.sum_l2_lo ? 1 : 0);
+            a.sum_l2_lo = lo;
+        }
         account(r);
         uint64_t late = 0;
         if (r.ctr.n_stragglers) {
+            uint64_t n_list = r.ctr.n_stragglers;
+            if (merge_lanes) {
+                // (group base, member mask) pairs -> problem offsets, ascending
+                std::vector<uint32_t> pairs(2 * r.ctr.straggler_classes);
+                HIPCHK(h, hipMemcpy(pairs.data(), d_strag.p, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                std::vector<uint32_t> offs;
+                offs.reserve(n_list);
+                for (size_t c = 0; c + 1 < pairs.size(); c += 2)
+                    for (uint32_t left = pairs[c + 1]; left; left &= left - 1) offs.push_back(pairs[c] + (uint32_t)__builtin_ctz(left));
+                std::sort(offs.begin(), offs.end());
+                n_list = offs.size();
+                HIPCHK(h, hipMemcpy(d_strag.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
             AttractParams S = Q;
-            S.count = r.ctr.n_stragglers;
+            S.count = n_list;
             S.offsets = d_strag.p;
             S.stragglers = nullptr;
+            S.merge = 0;
             AttractRun rs;
             if (int rc = launch_attract_pass(h, S, false, d_log, &merged, rs)) return rc;
             account(rs);

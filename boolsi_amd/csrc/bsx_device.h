@@ -84,6 +84,7 @@ struct Counters {               // zeroed before every launch
     unsigned int step_limit_hits;
     unsigned long long n_stragglers;    // fast kernel: problems handed to the general kernel
     unsigned long long n_cache_resolved;// general kernel: problems that ended on a cached cycle state
+    unsigned long long straggler_classes;   // lean kernel with merging: (group, member mask) pairs in the straggler list
     unsigned int straggler_overflow;
     unsigned int pad;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
@@ -107,7 +108,9 @@ constexpr uint32_t kCycleClaimSlots = 8192;       // fingerprints of published k
 // the general kernel.
 constexpr int kTagAcc = 3;
 constexpr uint32_t kLdsAcc = 61;
-constexpr uint32_t lean_acc_bytes(uint32_t nw) { return (kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4 + 4 * nw) + 16; }
+// + the per-wave tables of the sibling merge (64 lane ids + 64 member-mask accumulators per wave)
+constexpr uint32_t kMergeGroup = 32;            // consecutive problems loaded together; members tracked as a 32-bit mask
+constexpr uint32_t lean_acc_bytes(uint32_t nw) { return (kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4 + 4 * nw) + 16 + kWavesPerBlock * (64 + 256); }
 
 struct CycleRecord {
     uint32_t key[kMaxW32];
@@ -141,7 +144,9 @@ struct AttractParams {
     uint32_t* stragglers;       // fast kernel: offsets of problems that hit no cached cycle state
     uint64_t stragglers_cap;
     uint32_t fast_steps;        // FAST phase length
-    uint32_t pad;
+    uint32_t pad;               // lean kernel: service-lane override (0 = default)
+    uint32_t merge;             // lean kernel: merge sibling trajectories that reach the same state (stragglers become pairs)
+    uint32_t pad2;
 };
 
 struct HitRec { uint64_t offset; uint64_t t; };

@@ -57,6 +57,14 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl + kAccs);
     uint32_t* lamtab = acc_cnt + kAccs;
     uint32_t* keytab = lamtab + kAccs;
+    // sibling merge: per-wave tables -- 64 member-mask accumulators, then 64 one-byte lane ids
+    const bool merge = P.merge != 0;                        // uniform
+    uint32_t* dd_acc = keytab + kAccs * NW + (uint32_t)(threadIdx.x >> 6) * 80u;    // 80 words = 256 + 64 bytes per wave
+    // the same tables as LDS-address-space pointers (volatile ds_* accesses instead of flat ones)
+    typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
+    typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
+    lds_vu32* const dd_acc3 = (lds_vu32*)(__attribute__((address_space(3))) uint32_t*)dd_acc;
+    lds_vu8* const dd_ids3 = (lds_vu8*)(dd_acc3 + 64);
 
     uint32_t fm0[NW], fv0[NW];
     uint32_t any_fixed = 0;
@@ -65,6 +73,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     const bool has_fixed = any_fixed != 0;                  // uniform
     for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
     for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
+    dd_acc[lane] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         // only the first kAccs attractors of the journal enter the mirror, so every occupied slot is a
@@ -91,13 +100,16 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
 #pragma unroll
     for (int w = 0; w < NW; ++w) A[w] = 0;
     int32_t t = 0;                          // time relative to T_p; = mu once the lane has its hit
-    uint32_t res = kResIdle, my_p = 0;
+    // my_p: the lane's problem (offset in the launch); with merging the base of its group of kMergeGroup
+    // consecutive problems, and `members` the mask of those whose trajectories are in this lane's state
+    uint32_t res = kResIdle, my_p = 0, members = 1;
     uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
 #pragma unroll
     for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
     // steps of results that bypass the accumulators (lost, not found, longer than max_len); the steps
     // of accumulated results follow from the sums at the end
-    unsigned long long extra_ref = 0, extra_exec = 0;
+    unsigned long long extra_ref = 0;
+    uint32_t nexec = 0;                     // network updates this lane really executed (a merged lane steps once for all its members)
     uint32_t n_none = 0, n_capfail = 0;
     WaveQueue q{0, 0, true};
     uint32_t since_service = 0;
@@ -106,8 +118,11 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
 #endif
 
     // probe of state s: is it a cached cycle state?  -> the entry's tag word (0 = no)
+    uint32_t last_hash = 0;                 // full hash of the state probed last (reused by the merge)
     auto probe = [&](const uint32_t (&s)[NW]) -> uint32_t {
-        uint32_t h = hash_state<NW>(s) & cmask;
+        const uint32_t hfull = hash_state<NW>(s);
+        last_hash = hfull;
+        uint32_t h = hfull & cmask;
         const uint32_t* e = cbase + h * S;
         uint32_t et, d;
         // (the asm keeps the unused last word alive: a 16-byte ds_read_b128 takes 4 LDS cycles, the
@@ -154,7 +169,8 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
 #endif
         // a round is also forced every 32 iterations, so that lanes running past fast_steps are noticed
         // even when no lane of the wave ever gets free
-        if ((work_left && n_free >= service_lanes) || !running || ++since_service >= 32u) {
+        if ((work_left && n_free >= (merge && service_lanes < kMergeGroup ? kMergeGroup : service_lanes)) || !running ||
+            ++since_service >= 32u) {
             since_service = 0;
 #ifdef BSX_DIAG
             ++dbg_service;
@@ -163,12 +179,21 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
             if (res == 0 && t >= fast_steps) res = kResLost;    // no cached cycle state within fast_steps
             if (res != 0 && res != kResIdle) {
                 if (res == kResLost) {
-                    const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
-                    if (at < P.stragglers_cap) P.stragglers[at] = my_p;
-                    else atomicOr(&P.ctr->straggler_overflow, 1u);
-                    extra_exec += tp + (uint32_t)t;
+                    if (merge) {            // the class goes back as (group base, member mask)
+                        atomicAdd(&P.ctr->n_stragglers, (unsigned long long)__popc(members));
+                        const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
+                        if (2 * at + 1 < P.stragglers_cap) { P.stragglers[2 * at] = my_p; P.stragglers[2 * at + 1] = members; }
+                        else atomicOr(&P.ctr->straggler_overflow, 1u);
+                    } else {
+                        const unsigned long long at = atomicAdd(&P.ctr->n_stragglers, 1ull);
+                        if (at < P.stragglers_cap) P.stragglers[at] = my_p;
+                        else atomicOr(&P.ctr->straggler_overflow, 1u);
+                    }
+                    nexec += tp + (uint32_t)t;
                 } else {
                     const uint32_t tg = res & kTagMask, mu = (uint32_t)t, traj = tp + mu;
+                    const uint32_t m = (uint32_t)__popc(members);       // trajectories that share this result
+                    nexec += traj;
                     const uint32_t lam = lamtab[tg - 1];
                     const bool found = mu <= cap_rel && lam <= cap_rel - mu;
                     const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
@@ -181,28 +206,31 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
                             for (int w = 0; w < NW; ++w) r.key[w] = keytab[(tg - 1) * NW + w];
                         }
                         r.length = keep ? lam : 0; r.trajectory_l = keep ? traj : 0; r.found = keep; r.pad = 0;
-                        P.per_problem[my_p] = r;
+                        if (merge) {
+                            for (uint32_t left = members; left; left &= left - 1) P.per_problem[my_p + (uint32_t)__builtin_ctz(left)] = r;
+                        } else {
+                            P.per_problem[my_p] = r;
+                        }
                     }
                     if (__builtin_expect(!keep, 0)) {
-                        ++n_none;
-                        n_capfail += found ? 0u : 1u;                       // these add max_t each at the end
-                        extra_exec += traj;
-                        extra_ref += found ? (unsigned long long)(traj + lam) : 0ull;   // model.py:201
+                        n_none += m;
+                        n_capfail += found ? 0u : m;                        // these add max_t each at the end
+                        extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
                     } else {
-                        const uint32_t sq = traj * traj;
+                        const uint32_t wl = m * traj, wsq = wl * traj;      // weighted by the members
                         bool in_regs = false;
 #pragma unroll
                         for (int j = 0; j < kTagAcc; ++j) {
-                            const bool m = tg == (uint32_t)(j + 1) && tsl2[j] < kRegSumGuard;
-                            tcnt[j] += m ? 1u : 0u;
-                            tsl[j] += m ? traj : 0u;
-                            tsl2[j] += m ? sq : 0u;
-                            in_regs = in_regs || m;
+                            const bool here = tg == (uint32_t)(j + 1) && tsl2[j] < kRegSumGuard;
+                            tcnt[j] += here ? m : 0u;
+                            tsl[j] += here ? wl : 0u;
+                            tsl2[j] += here ? wsq : 0u;
+                            in_regs = in_regs || here;
                         }
                         if (!in_regs) {
-                            atomicAdd(&acc_cnt[tg - 1], 1u);
-                            atomicAdd(&acc_sl[tg - 1], (unsigned long long)traj);
-                            atomicAdd(&acc_sl2[tg - 1], (unsigned long long)sq);
+                            atomicAdd(&acc_cnt[tg - 1], m);
+                            atomicAdd(&acc_sl[tg - 1], (unsigned long long)wl);
+                            atomicAdd(&acc_sl2[tg - 1], (unsigned long long)wsq);
                         }
                     }
                 }
@@ -218,14 +246,19 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
                 const uint64_t idle = __ballot(res == kResIdle);
                 if (avail && idle) {
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
-                    if (res == kResIdle && rank < avail) {
-                        my_p = (uint32_t)(q.next + rank);
-                        init_problem_simple<NW>(P.sp, (uint64_t)my_p, A);
+                    // with merging whole groups of kMergeGroup consecutive problems are loaded together (chunks
+                    // start on group boundaries), so that their members share a clock and a member mask
+                    uint64_t take = (uint64_t)__popcll(idle);
+                    if (merge) take &= ~(uint64_t)(kMergeGroup - 1);
+                    if (res == kResIdle && rank < take && rank < avail) {
+                        const uint32_t off = (uint32_t)(q.next + rank);
+                        init_problem_simple<NW>(P.sp, (uint64_t)off, A);
+                        my_p = merge ? (off & ~(kMergeGroup - 1)) : off;
+                        members = merge ? 1u << (off & (kMergeGroup - 1)) : 1u;
                         t = -(int32_t)tp;
                         res = has_warmup ? 0u : probe(A);       // s(T_p) = s(0) itself may be a cycle state: mu = 0
                     }
-                    const uint64_t n_idle = (uint64_t)__popcll(idle);
-                    q.next += n_idle < avail ? n_idle : avail;
+                    q.next += take < avail ? take : avail;
                 }
             }
         }       // no `continue`: one back edge keeps the loop-carried registers in place (no copy chains)
@@ -244,6 +277,44 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
 #pragma unroll
             for (int w = 0; w < NW; ++w) A[w] = nxt[w];
             res = et;               // 0 = keep running; running too long is noticed in the service round
+        }
+
+        // ---- sibling merge: trajectories of one group that are in the same state (at the same time: they
+        //      were loaded together) continue as one lane with the union of their member masks.  Each
+        //      running lane posts its id in a per-wave slot picked by the state's hash; whoever reads another
+        //      lane's id there compares states through ds_bpermute and, if equal, hands its members over.
+        //      (Lanes on a cached cycle state were resolved by the probe above and take no part, so every
+        //      member of a merged lane has the same mu.  A slot collision only postpones a merge.)
+        if (merge) {
+            const bool cand = res == 0;
+            // (sibling states differ in a few bits, so the slot needs a mixing hash: two multiplies per iteration)
+            const uint32_t slot = (((last_hash ^ (my_p * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 26);
+            // (volatile: the compiler must not forward a lane's own store to its load -- another lane's
+            //  store to the same slot may have come later)
+            if (cand) dd_ids3[slot] = (uint8_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t w = cand ? (uint32_t)dd_ids3[slot] : (uint32_t)lane;
+            // every lane takes part in the permutes (a lane masked off would deliver nothing to its readers),
+            // so they come before any short-circuit logic
+            uint32_t differ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)my_p) ^ my_p;
+            differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)res);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)A[i]) ^ A[i];
+            const bool same = cand & (w != (uint32_t)lane) & (differ == 0u);
+            if (__ballot(same)) {                       // uniform: most iterations of old lanes merge nothing
+                if (same) {
+                    atomicOr(&dd_acc[w], members);
+                    nexec += tp + (uint32_t)t;          // the steps this lane did on its own
+                    res = kResIdle;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (res == 0) {
+                    const uint32_t got = dd_acc3[lane];
+                    if (got) { members |= got; dd_acc3[lane] = 0; }
+                }
+            }
         }
     }
 
@@ -265,14 +336,13 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
         for (int w = 0; w < NW; ++w) k[w] = keytab[a * NW + w];
         const unsigned long long sl = acc_sl[a];
         log_append<NW>(P, k, lamtab[a], cn, sl, acc_sl2[a]);
-        extra_exec += sl;                                                       // sum of T_p + mu
         extra_ref += sl + (unsigned long long)cn * lamtab[a];                   // + lambda each (model.py:201)
     }
 #ifdef BSX_DIAG
     if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_service); }
 #endif
     wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), lane);
-    wave_atomic_add(&P.ctr->steps_exec, extra_exec, lane);
+    wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, lane);
     wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, lane);
 }
 

@@ -24,16 +24,20 @@ from util import load, t_of, compile_case, contiguous_runs, GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['cycle_cache', 'no_cycle_cache'])
+@pytest.fixture(scope='module', params=['cycle_cache', 'cycle_cache_no_merge', 'no_cycle_cache'])
 def eng(request):
-    """Every test runs twice: with the cycle-state cache (trajectories end at mu on a cached cycle
-    state) and without it (every trajectory runs Brent's detector + the mu pass)."""
+    """Every test runs three times: with the cycle-state cache (trajectories end at mu on a cached cycle
+    state; sibling trajectories that reach the same state are merged), the same without the merge, and
+    without the cache (every trajectory runs Brent's detector + the mu pass)."""
     from boolsi_amd.engine import Engine
-    os.environ['BSX_CYCLE_CACHE'] = '1' if request.param == 'cycle_cache' else '0'
+    os.environ['BSX_CYCLE_CACHE'] = '0' if request.param == 'no_cycle_cache' else '1'
     e = Engine(0)
-    e.cycle_cache = request.param == 'cycle_cache'
+    e.cycle_cache = request.param != 'no_cycle_cache'
     os.environ.pop('BSX_CYCLE_CACHE')
+    if request.param == 'cycle_cache_no_merge':
+        os.environ['BSX_MERGE'] = '0'           # read per attract call: lean kernel without the sibling merge
     yield e
+    os.environ.pop('BSX_MERGE', None)
     e.close()
 
 
