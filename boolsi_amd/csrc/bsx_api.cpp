@@ -28,6 +28,9 @@ hipError_t launch_compact(const uint32_t* t_hit, uint64_t count, uint32_t* seg_c
                           HitRec* hits, uint64_t hits_cap, bool write_pass, hipStream_t st);
 hipError_t configure_attract(int nw, int k, int lut_mode, size_t shmem);
 hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
+hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
+hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
+size_t pool_extra_bytes(uint32_t nw);
 hipError_t configure_target(int nw, int k, int lut_mode, size_t shmem);
 hipError_t configure_simulate(int nw, int k, int lut_mode, size_t shmem);
 }  // namespace bsx
@@ -79,6 +82,9 @@ struct bsx_engine {
     bool cache_enabled = true;
     int lean_blocks_per_cu = 0;  // occupancy of the lean attract kernel for the current network
     bool fast_ok = true;        // cleared when the lean kernel's straggler list overflowed for this space
+    bool pool_ok = false;       // the class-pool kernel fits the LDS for this network
+    size_t cache_stride = 0;    // bytes per slot of the LDS cache mirror
+    std::vector<CycleRecord> h_journal;
     uint32_t fast_steps = 0;    // lean kernel: steps without a cached cycle state before a problem is handed over (0 = default)
     bool fast_calibrated = false;
     uint32_t cache_lds_slots = 0;
@@ -320,6 +326,14 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
     h->shmem_attract = h->shmem + cache_bytes;
     HIPCHK(h, configure_attract((int)nw, (int)k_mux, h->lut_mode, h->shmem_attract));
     HIPCHK(h, configure_attract_fast((int)nw, (int)k_mux, h->lut_mode, h->shmem_attract, &h->lean_blocks_per_cu));
+    h->cache_stride = cache_stride;
+    {   // class-pool kernel: available when it fits next to the smallest useful mirror (64 slots)
+        const size_t pool_max = h->shmem + (size_t)slots * cache_stride + 32 + pool_extra_bytes(nw);
+        const size_t pool_min = h->shmem + (size_t)64 * cache_stride + 32 + pool_extra_bytes(nw);
+        h->pool_ok = pool_min <= 160 * 1024 - 1024;
+        int blocks = 0;
+        if (h->pool_ok) HIPCHK(h, configure_attract_pool((int)nw, (int)k_mux, h->lut_mode, std::min<size_t>(pool_max, 160 * 1024 - 1024), &blocks));
+    }
     if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] network: nw %u k_mux %u lut mode %d (0 L2 bytes, 1 LDS bytes, 2 LDS nibbles) shmem %zu attract shmem %zu lean blocks/CU %d\n", nw, k_mux, (int)h->lut_mode, h->shmem, h->shmem_attract, h->lean_blocks_per_cu);
     HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_mode, h->shmem));
     HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_mode, h->shmem));
@@ -401,6 +415,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_claims.p, 0, sizeof(unsigned int) * kCycleClaimSlots));
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     h->fast_ok = true;
+    h->h_journal.clear();
     h->fast_steps = 0;
     h->fast_calibrated = false;
     sp.n_any = n_any;
@@ -499,9 +514,44 @@ struct AttractRun {
 };
 
 // One k_attract launch (general or fast) + merge of its log into `merged` unless `discard_log`.
-int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec>& d_log, MergedTable* merged,
+enum PassKind { kPassGeneral = 0, kPassLean = 1, kPassPool = 2 };
+
+// LDS mirror size for the lean / pool kernels: they fill the mirror once from the journal, so it only has
+// to hold what the journal holds (4 slots per state keeps probe chains short); a smaller mirror leaves
+// the LDS to more workgroups.  The general kernel inserts while it runs and keeps the full size.
+int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
+    unsigned int known = 0;
+    HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+    known = std::min<unsigned int>(known, kCycleJournalCap);
+    if (h->h_journal.size() != known) {
+        h->h_journal.resize(known);
+        if (known) HIPCHK(h, hipMemcpy(h->h_journal.data(), h->d_cc_journal.p, known * sizeof(CycleRecord), hipMemcpyDeviceToHost));
+    }
+    uint64_t states = 0;
+    uint32_t taken = 0;
+    for (const CycleRecord& r : h->h_journal) {
+        if (taken >= (uint32_t)kTagAcc + kLdsAcc) break;
+        if (!r.ready || r.length == 0 || r.length > kCycleCacheMaxLen) continue;
+        states += r.length;
+        ++taken;
+    }
+    uint32_t slots = 64;
+    while (slots < 4 * states && slots < h->cache_lds_slots) slots *= 2;
+    *slots_out = std::min(slots, h->cache_lds_slots);
+    return BSX_OK;
+}
+
+int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>& d_log, MergedTable* merged,
                         AttractRun& run) {
-    const Launch L = plan_persistent(h, P.count, h->shmem_attract);
+    const bool fast = kind != kPassGeneral;
+    size_t shmem = h->shmem_attract;
+    if (fast) {
+        uint32_t slots = h->cache_lds_slots;
+        if (int rc = lean_mirror_slots(h, &slots)) return rc;
+        P.cc.lds_slots = slots;
+        shmem = h->shmem + (size_t)slots * h->cache_stride + 32 + (kind == kPassPool ? pool_extra_bytes(h->net.nw) : lean_acc_bytes(h->net.nw));
+    }
+    const Launch L = plan_persistent(h, P.count, shmem);
     P.chunk = L.chunk;
     if (const char* c = std::getenv("BSX_CHUNK")) P.chunk = (uint32_t)std::max(64, std::atoi(c));     // tuning knob
     const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
@@ -511,15 +561,16 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, bool fast, DevBuf<LogRec
     P.log_cap = log_cap;
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (fast) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, h->shmem_attract, h->stream, P));
-    else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, h->shmem_attract, h->stream, P));
+    if (kind == kPassPool) HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+    else if (kind == kPassLean) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+    else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
     if (std::getenv("BSX_DEBUG"))
         std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu stragglers, %.3f ms (BSX_DIAG build: %llu wave iterations, %llu service rounds)\n",
-                     fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
+                     kind == kPassPool ? "pool" : fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
                      (unsigned long long)run.ctr.n_stragglers, run.ms, (unsigned long long)run.ctr.wave_iters,
                      (unsigned long long)run.ctr.service_rounds);
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
@@ -636,7 +687,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             Q.offsets = d_sample.p;
             Q.per_problem = nullptr;
             AttractRun r;
-            if (int rc = launch_attract_pass(h, Q, false, d_log, nullptr, r)) return rc;
+            if (int rc = launch_attract_pass(h, Q, kPassGeneral, d_log, nullptr, r)) return rc;
             kernel_ms += r.ms; ++launches; steps_exec += r.ctr.steps_exec;
             HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
             if (known == 0) use_fast = false;           // nothing cacheable was found
@@ -646,9 +697,12 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // through the detector right after each tile, which also teaches the cache for the next tile.
     // The first tiles of a space are small probes: if most of their stragglers did end on a cached
     // cycle state (just later than the FAST length), the FAST length is quadrupled for what follows.
-    // BSX_MERGE=0: lean kernel without the sibling merge (A/B runs, tests)
+    // BSX_MERGE: 2 (default) class-pool kernel, 1 lean kernel with the in-lane sibling merge, 0 lean kernel
+    // without merging (A/B runs, tests)
     const char* merge_env = std::getenv("BSX_MERGE");
-    const bool merge_lanes = !(merge_env && merge_env[0] == '0');
+    int merge_mode = merge_env ? std::atoi(merge_env) : 2;
+    if (merge_mode == 2 && !h->pool_ok) merge_mode = 1;
+    const bool merge_lanes = merge_mode != 0;
     while (use_fast && h->fast_ok && done < count) {
         const uint64_t tile = std::min<uint64_t>(count - done, h->fast_calibrated ? kLeanTile : kProbeTile);
         DevBuf<uint32_t>& d_strag = h->d_strag;
@@ -663,7 +717,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         Q.stragglers_cap = tile;
         AttractRun r;
         MergedTable tile_table;         // folded into `merged` only if the pass is accepted
-        if (int rc = launch_attract_pass(h, Q, true, d_log, &tile_table, r)) return rc;
+        if (int rc = launch_attract_pass(h, Q, merge_mode == 2 ? kPassPool : kPassLean, d_log, &tile_table, r)) return rc;
         if (r.ctr.straggler_overflow) {
             // more (group, mask) pairs than the list holds: the cache does not cover this space.  Drop the
             // pass and give the rest of the range to the detector.
@@ -686,13 +740,16 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         if (r.ctr.n_stragglers) {
             uint64_t n_list = r.ctr.n_stragglers;
             if (merge_lanes) {
-                // (group base, member mask) pairs -> problem offsets, ascending
-                std::vector<uint32_t> pairs(2 * r.ctr.straggler_classes);
+                // (group base, member mask words) records -> problem offsets, ascending
+                const size_t rec = merge_mode == 2 ? 3 : 2;     // the pool kernel's groups have 64 members
+                std::vector<uint32_t> pairs(rec * r.ctr.straggler_classes);
                 HIPCHK(h, hipMemcpy(pairs.data(), d_strag.p, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 std::vector<uint32_t> offs;
                 offs.reserve(n_list);
-                for (size_t c = 0; c + 1 < pairs.size(); c += 2)
-                    for (uint32_t left = pairs[c + 1]; left; left &= left - 1) offs.push_back(pairs[c] + (uint32_t)__builtin_ctz(left));
+                for (size_t c = 0; c + rec <= pairs.size(); c += rec)
+                    for (size_t wd = 1; wd < rec; ++wd)
+                        for (uint32_t left = pairs[c + wd]; left; left &= left - 1)
+                            offs.push_back(pairs[c] + (uint32_t)(32 * (wd - 1)) + (uint32_t)__builtin_ctz(left));
                 std::sort(offs.begin(), offs.end());
                 n_list = offs.size();
                 HIPCHK(h, hipMemcpy(d_strag.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -703,7 +760,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             S.stragglers = nullptr;
             S.merge = 0;
             AttractRun rs;
-            if (int rc = launch_attract_pass(h, S, false, d_log, &merged, rs)) return rc;
+            if (int rc = launch_attract_pass(h, S, kPassGeneral, d_log, &merged, rs)) return rc;
             account(rs);
             late = rs.ctr.n_cache_resolved;
         }
@@ -722,7 +779,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         Q.count = count - done;
         Q.per_problem = per_problem ? d_pp.p + done : nullptr;
         AttractRun r;
-        if (int rc = launch_attract_pass(h, Q, false, d_log, &merged, r)) return rc;
+        if (int rc = launch_attract_pass(h, Q, kPassGeneral, d_log, &merged, r)) return rc;
         account(r);
     }
 

@@ -110,7 +110,8 @@ constexpr int kTagAcc = 3;
 constexpr uint32_t kLdsAcc = 61;
 // + the per-wave tables of the sibling merge (64 lane ids + 64 member-mask accumulators per wave)
 constexpr uint32_t kMergeGroup = 32;            // consecutive problems loaded together; members tracked as a 32-bit mask
-constexpr uint32_t lean_acc_bytes(uint32_t nw) { return (kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4 + 4 * nw) + 16 + kWavesPerBlock * (64 + 256); }
+constexpr uint32_t kMergeSlots = 256;          // per wave: one-byte lane ids, picked by (group & 3, 6 hash bits)
+constexpr uint32_t lean_acc_bytes(uint32_t nw) { return (kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4 + 4 * nw) + 16 + kWavesPerBlock * (kMergeSlots + 256); }
 
 struct CycleRecord {
     uint32_t key[kMaxW32];

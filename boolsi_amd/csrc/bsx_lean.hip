@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
     uint32_t* keytab = lamtab + kAccs;
     // sibling merge: per-wave tables -- 64 member-mask accumulators, then 64 one-byte lane ids
     const bool merge = P.merge != 0;                        // uniform
-    uint32_t* dd_acc = keytab + kAccs * NW + (uint32_t)(threadIdx.x >> 6) * 80u;    // 80 words = 256 + 64 bytes per wave
+    uint32_t* dd_acc = keytab + kAccs * NW + (uint32_t)(threadIdx.x >> 6) * (64u + kMergeSlots / 4u);      // 256 B + the id bytes per wave
     // the same tables as LDS-address-space pointers (volatile ds_* accesses instead of flat ones)
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
         if (merge) {
             const bool cand = res == 0;
             // (sibling states differ in a few bits, so the slot needs a mixing hash: two multiplies per iteration)
-            const uint32_t slot = (((last_hash ^ (my_p * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 26);
+            // resident groups are mostly consecutive, so two group bits keep them out of each other's slots
+            const uint32_t slot = ((last_hash * 0x85EBCA6Bu) >> 26) | (((my_p >> 5) & 3u) << 6);
             // (volatile: the compiler must not forward a lane's own store to its load -- another lane's
             //  store to the same slot may have come later)
             if (cand) dd_ids3[slot] = (uint8_t)lane;

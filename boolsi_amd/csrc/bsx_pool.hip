@@ -1,0 +1,358 @@
+// Attract sweep kernel with a class pool: sibling trajectories that meet are stepped once.
+#include "bsx_kernels_common.h"
+
+namespace bsx {
+
+// ------------------------------------------------------------------------------------------------
+// k_attract_pool: attract.py:262-302 semantics for the problems that the lean kernel (bsx_lean.hip)
+// covers -- plain enumeration, attractors cached -- when no per-lane bookkeeping has to survive an
+// iteration.  Same results, same straggler hand-over to the general kernel; what changes is which
+// network updates are executed.
+//
+// Observation: a sweep enumerates initial states that differ in a few low bits.  In an ordered or
+// critical network most of those differences die out within a step or two, i.e. sibling trajectories
+// run into the SAME state at the SAME time and are identical from there on (north-star network: the 64
+// states of an aligned group of 64 problems are 9.5 distinct states after one update, 3.8 after three).
+// A "class" is such a set of trajectories: (state, time, group base, 64-bit member mask).  A class is
+// stepped once; when its state is a cached cycle state at time t every member has mu = t (classes on a
+// cycle are resolved before they can take part in a merge, so no member was on the cycle earlier),
+// and count / sum l / sum l^2 grow by m, m*l, m*l^2 with m = popcount(members).
+//
+// Each wave keeps its classes in a ring buffer in LDS (the pool) and runs one of two stages per
+// iteration, all 64 lanes doing one network update either way:
+//   fresh stage: the next 64 consecutive problems -- init, lookup of s(T_p) itself, update, lookup;
+//   pool stage (when the pool holds at least 64 classes, or the input is used up): the 64 oldest
+//                classes -- update, lookup.
+// After the lookup: resolved lanes are accumulated, lanes past the FAST length go to the straggler list
+// as (group base, member mask), the rest is deduplicated (lanes of one group in the same state merge
+// their masks: per-wave hash slots + ds_bpermute compare, as in the lean kernel) and the survivors are
+// appended to the pool.  Nothing but the accumulators lives in registers across iterations, so there is
+// no per-lane state machine and no service round.
+constexpr uint32_t kPoolCap = 128;              // classes per wave (ring buffer, power of two)
+constexpr uint32_t kPoolGroup = 64;             // problems loaded together = lanes
+
+constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // state, group base, members lo/hi, time
+constexpr int pool_min_waves(int nw) { return nw <= 2 ? 4 : 2; }
+
+template <int NW, int K, int LM>
+__global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(const AttractParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
+    const bool has_warmup = tp != 0;
+    const int32_t fast_steps = (int32_t)P.fast_steps;
+    const uint32_t cmask = P.cc.lds_slots - 1;
+    constexpr int S = CacheLayout<NW>::kStride;
+    constexpr uint32_t kAccs = (uint32_t)kTagAcc + kLdsAcc;
+    constexpr uint32_t R = pool_rec_words(NW);
+
+    // LDS: [network tables][cache mirror][per attractor: sum l^2, sum l (u64), count, length (u32), key]
+    //      [per wave: pool records | 64 x 8 B member accumulators | 256 one-byte lane ids]
+    uint32_t* lc = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);
+    const uint32_t lc_words = kCacheHeaderWords + P.cc.lds_slots * S;
+    unsigned long long* acc_sl2 = reinterpret_cast<unsigned long long*>(lc + ((lc_words + 1u) & ~1u));
+    unsigned long long* acc_sl = acc_sl2 + kAccs;
+    unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl + kAccs);
+    uint32_t* lamtab = acc_cnt + kAccs;
+    uint32_t* keytab = lamtab + kAccs;
+    constexpr uint32_t kWaveWords = kPoolCap * R + 128 + kMergeSlots / 4;
+    uint32_t* wave_base = keytab + ((kAccs * NW + 1u) & ~1u) + wave * kWaveWords;
+    typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
+    typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
+    lds_vu32* const pool = (lds_vu32*)(__attribute__((address_space(3))) uint32_t*)wave_base;
+    lds_vu32* const dd_acc = pool + kPoolCap * R;           // [64][2]
+    lds_vu8* const dd_ids = (lds_vu8*)(dd_acc + 128);
+
+    uint32_t fm0[NW], fv0[NW];
+    uint32_t any_fixed = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; any_fixed |= fm0[w]; }
+    const bool has_fixed = any_fixed != 0;                  // uniform
+    for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
+    dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t seen = 0, n_states = 0, n_attr = 0;
+        cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, seen, n_states, n_attr, kAccs);
+    }
+    __syncthreads();
+    const uint32_t* cbase = lc + kCacheHeaderWords;
+    for (uint32_t sl = threadIdx.x; sl < P.cc.lds_slots; sl += blockDim.x) {
+        const uint32_t tg = cbase[sl * S + NW] & kTagMask;
+        if (tg) {
+            lamtab[tg - 1] = cbase[sl * S + NW + 1];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) keytab[(tg - 1) * NW + w] = cbase[sl * S + NW + 2 + w];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t cap_rel = (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)(P.max_t - tp);
+
+    uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
+#pragma unroll
+    for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
+    unsigned long long extra_ref = 0;
+    uint32_t nexec = 0, n_none = 0, n_capfail = 0;
+    WaveQueue q{0, 0, true};
+    uint32_t head = 0, count = 0;                           // pool ring (uniform)
+#ifdef BSX_DIAG
+    unsigned long long dbg_iters = 0, dbg_fresh = 0;
+#endif
+
+    // is `s` a cached cycle state?  -> the entry's tag word (0 = no); `hfull` = the state's hash
+    auto probe = [&](const uint32_t (&s)[NW], uint32_t& hfull) -> uint32_t {
+        hfull = hash_state<NW>(s);
+        uint32_t h = hfull & cmask;
+        const uint32_t* e = cbase + h * S;
+        uint32_t et, d;
+        if constexpr (NW == 1) {
+            uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+            asm volatile("" : "+v"(v.z), "+v"(v.w));
+            d = v.x ^ s[0]; et = v.y;
+        } else if constexpr (NW == 2) {
+            uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
+            asm volatile("" : "+v"(v.w));
+            d = (v.x ^ s[0]) | (v.y ^ s[1]); et = v.z;
+        } else {
+            d = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) d |= e[w] ^ s[w];
+            et = e[NW];
+        }
+        bool hit = (d == 0) & (et != 0);
+        bool walking = (et >> 31) != 0 && !hit;
+        if (__builtin_expect(__ballot(walking) != 0, 0)) {
+            while (walking) {
+                h = (h + 1) & cmask;
+                const uint32_t* f = cbase + h * S;
+                uint32_t d2 = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) d2 |= f[w] ^ s[w];
+                const uint32_t ft = f[NW];
+                const bool here = (d2 == 0) & (ft != 0);
+                if (here) { hit = true; et = ft; }
+                walking = (ft >> 31) != 0 && !here;
+            }
+        }
+        return hit ? et : 0u;
+    };
+
+    for (;;) {
+        const bool input = q.more || q.next < q.end;
+        if (!input && count == 0) break;
+#ifdef BSX_DIAG
+        ++dbg_iters;
+#endif
+        uint32_t A[NW], base = 0, mlo = 0, mhi = 0, res = 0, hfull = 0;
+        int32_t t = 0;
+        bool live = false;
+        if (count > kPoolCap - kPoolGroup || !input) {
+            // ---- pool stage: the oldest classes (their states were looked up when they were stored)
+            const uint32_t n = count < 64u ? count : 64u;
+            live = lane < n;
+            const uint32_t r = ((head + lane) & (kPoolCap - 1)) * R;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) A[w] = live ? pool[r + w] : 0u;
+            base = pool[r + NW]; mlo = pool[r + NW + 1]; mhi = pool[r + NW + 2]; t = (int32_t)pool[r + NW + 3];
+            head = (head + n) & (kPoolCap - 1);
+            count -= n;
+        } else {
+            // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
+            if (q.next == q.end) {
+                const uint64_t b = grab_chunk(&P.ctr->cursor, P.chunk, (int)lane);
+                if (b >= P.count) { q.more = false; continue; }
+                q.next = b; q.end = (b + P.chunk < P.count) ? b + P.chunk : P.count;
+            }
+            const uint64_t avail = q.end - q.next;
+            const uint32_t n = avail < 64u ? (uint32_t)avail : 64u;
+            live = lane < n;
+            base = (uint32_t)q.next;
+            init_problem_simple<NW>(P.sp, q.next + lane, A);
+            mlo = lane < 32u ? 1u << lane : 0u;
+            mhi = lane < 32u ? 0u : 1u << (lane - 32u);
+            t = -(int32_t)tp;
+            q.next += n;
+            if (!has_warmup) res = live ? probe(A, hfull) : 0u;      // s(T_p) = s(0) itself may be a cycle state: mu = 0
+#ifdef BSX_DIAG
+            ++dbg_fresh;
+#endif
+        }
+
+        // ---- one update per live, unresolved lane, then the lookup of the new state
+        if (live && res == 0) {
+            uint32_t nxt[NW];
+            net_step<NW, K>(nv, A, fm0, fv0, nxt, has_fixed);
+            ++t;
+            ++nexec;
+            if (has_warmup) {
+                if (t <= 0) apply_perturbations<NW>(P.sp, (uint32_t)((int32_t)tp + t), 0ull, nxt);
+            }
+            uint32_t et = probe(nxt, hfull);
+            if (has_warmup) et = t >= 0 ? et : 0u;          // states before T_p do not count
+#pragma unroll
+            for (int w = 0; w < NW; ++w) A[w] = nxt[w];
+            res = et;
+        }
+
+        // ---- resolved classes: every member has mu = t
+        const uint32_t m = (uint32_t)(__popc(mlo) + __popc(mhi));
+        if (live && res != 0) {
+            const uint32_t tg = res & kTagMask, mu = (uint32_t)t, traj = tp + mu;
+            const uint32_t lam = lamtab[tg - 1];
+            const bool found = mu <= cap_rel && lam <= cap_rel - mu;
+            const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
+            if (P.per_problem) {
+                ProblemRec32 r;
+#pragma unroll
+                for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
+                if (keep) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) r.key[w] = keytab[(tg - 1) * NW + w];
+                }
+                r.length = keep ? lam : 0; r.trajectory_l = keep ? traj : 0; r.found = keep; r.pad = 0;
+                for (uint32_t left = mlo; left; left &= left - 1) P.per_problem[base + (uint32_t)__builtin_ctz(left)] = r;
+                for (uint32_t left = mhi; left; left &= left - 1) P.per_problem[base + 32u + (uint32_t)__builtin_ctz(left)] = r;
+            }
+            if (__builtin_expect(!keep, 0)) {
+                n_none += m;
+                n_capfail += found ? 0u : m;
+                extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
+            } else {
+                const uint32_t wl = m * traj, wsq = wl * traj;
+                bool in_regs = false;
+#pragma unroll
+                for (int j = 0; j < kTagAcc; ++j) {
+                    const bool here = tg == (uint32_t)(j + 1) && tsl2[j] < 0x7FFF0000u;
+                    tcnt[j] += here ? m : 0u;
+                    tsl[j] += here ? wl : 0u;
+                    tsl2[j] += here ? wsq : 0u;
+                    in_regs = in_regs || here;
+                }
+                if (!in_regs) {
+                    atomicAdd(&acc_cnt[tg - 1], m);
+                    atomicAdd(&acc_sl[tg - 1], (unsigned long long)wl);
+                    atomicAdd(&acc_sl2[tg - 1], (unsigned long long)wsq);
+                }
+            }
+        }
+        // ---- classes past the FAST length go back as (group base, member mask)
+        bool cand = live && res == 0;
+        if (cand && t >= fast_steps) {
+            atomicAdd(&P.ctr->n_stragglers, (unsigned long long)m);
+            const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
+            if (3 * at + 2 < P.stragglers_cap) { P.stragglers[3 * at] = base; P.stragglers[3 * at + 1] = mlo; P.stragglers[3 * at + 2] = mhi; }
+            else atomicOr(&P.ctr->straggler_overflow, 1u);
+            cand = false;
+        }
+
+        // ---- merge lanes of one group that are in the same state (same group = same time)
+        {
+            const uint32_t slot = (((hfull ^ (base * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 24);
+            if (cand) dd_ids[slot] = (uint8_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t w = cand ? (uint32_t)dd_ids[slot] : lane;
+            // every lane takes part in the permutes (a lane masked off would deliver nothing to its readers)
+            uint32_t differ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)base) ^ base;
+            differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)(cand ? 0u : 1u));
+            differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), t) ^ (uint32_t)t;      // (same group = same time in a FIFO pool; checked anyway)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)A[i]) ^ A[i];
+            const bool same = cand & (w != lane) & (differ == 0u);
+            if (__ballot(same)) {
+                if (same) {
+                    if (mlo) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
+                    if (mhi) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w + 1], mhi);
+                    cand = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (cand) {
+                    const uint32_t glo = dd_acc[2 * lane], ghi = dd_acc[2 * lane + 1];
+                    if (glo | ghi) { mlo |= glo; mhi |= ghi; dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0; }
+                }
+            }
+        }
+
+        // ---- survivors go (back) to the pool
+        const uint64_t keepers = __ballot(cand);
+        if (cand) {
+            const uint32_t rank = __popcll(keepers & ((1ull << lane) - 1ull));
+            const uint32_t r = ((head + count + rank) & (kPoolCap - 1)) * R;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pool[r + w] = A[w];
+            pool[r + NW] = base; pool[r + NW + 1] = mlo; pool[r + NW + 2] = mhi; pool[r + NW + 3] = (uint32_t)t;
+        }
+        count += (uint32_t)__popcll(keepers);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- epilogue: per-lane sums -> workgroup accumulators -> one log record per attractor and workgroup
+#pragma unroll
+    for (int j = 0; j < kTagAcc; ++j) {
+        if (tcnt[j]) {
+            atomicAdd(&acc_cnt[j], tcnt[j]);
+            atomicAdd(&acc_sl[j], (unsigned long long)tsl[j]);
+            atomicAdd(&acc_sl2[j], (unsigned long long)tsl2[j]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t a = threadIdx.x; a < kAccs; a += blockDim.x) {
+        const uint32_t cn = acc_cnt[a];
+        if (!cn) continue;
+        uint32_t k[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) k[w] = keytab[a * NW + w];
+        const unsigned long long sl = acc_sl[a];
+        log_append<NW>(P, k, lamtab[a], cn, sl, acc_sl2[a]);
+        extra_ref += sl + (unsigned long long)cn * lamtab[a];                   // + lambda each (model.py:201)
+    }
+#ifdef BSX_DIAG
+    if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_fresh); }
+#endif
+    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), (int)lane);
+    wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, (int)lane);
+    wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, (int)lane);
+}
+
+template <int NW, int K>
+static hipError_t launch_pool_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_attract_pool, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    void* args[] = {const_cast<AttractParams*>(&P)};
+    return hipLaunchKernel(fn, grid, dim3(kBlock), args, shmem, st);
+}
+template <int NW, int K>
+static hipError_t configure_pool_nk(int lut_mode, dim3, size_t shmem, hipStream_t, int& blocks_per_cu) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_attract_pool, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, shmem);
+}
+
+hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
+    BSX_DISPATCH(launch_pool_nk)
+}
+hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu) {
+    const dim3 grid(1);
+    const hipStream_t st = nullptr;
+    int& P = *blocks_per_cu;
+    BSX_DISPATCH(configure_pool_nk)
+}
+
+// bytes of LDS behind the cache mirror: per-attractor tables + per-wave pool, accumulators and id slots
+size_t pool_extra_bytes(uint32_t nw) {
+    const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16;
+    const size_t per_wave = ((size_t)kPoolCap * pool_rec_words(nw) + 128 + kMergeSlots / 4) * 4;
+    return tables + (size_t)kWavesPerBlock * per_wave;
+}
+
+}  // namespace bsx

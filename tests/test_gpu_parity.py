@@ -24,18 +24,19 @@ from util import load, t_of, compile_case, contiguous_runs, GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['cycle_cache', 'cycle_cache_no_merge', 'no_cycle_cache'])
+@pytest.fixture(scope='module', params=['cycle_cache', 'lean_merge', 'lean_plain', 'no_cycle_cache'])
 def eng(request):
-    """Every test runs three times: with the cycle-state cache (trajectories end at mu on a cached cycle
-    state; sibling trajectories that reach the same state are merged), the same without the merge, and
-    without the cache (every trajectory runs Brent's detector + the mu pass)."""
+    """Every test runs four times: with the cycle-state cache and the class-pool kernel (trajectories end
+    at mu on a cached cycle state; sibling trajectories that reach the same state are stepped once), with
+    the lean kernel and its in-lane merge, with the lean kernel without merging, and without the cache
+    (every trajectory runs Brent's detector + the mu pass)."""
     from boolsi_amd.engine import Engine
     os.environ['BSX_CYCLE_CACHE'] = '0' if request.param == 'no_cycle_cache' else '1'
     e = Engine(0)
     e.cycle_cache = request.param != 'no_cycle_cache'
     os.environ.pop('BSX_CYCLE_CACHE')
-    if request.param == 'cycle_cache_no_merge':
-        os.environ['BSX_MERGE'] = '0'           # read per attract call: lean kernel without the sibling merge
+    if request.param in ('lean_merge', 'lean_plain'):     # read per attract call; default = class-pool kernel
+        os.environ['BSX_MERGE'] = '1' if request.param == 'lean_merge' else '0' 
     yield e
     os.environ.pop('BSX_MERGE', None)
     e.close()
