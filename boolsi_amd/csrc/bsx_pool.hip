@@ -155,9 +155,18 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
             const uint32_t n = count < 64u ? count : 64u;
             live = lane < n;
             const uint32_t r = ((head + lane) & (kPoolCap - 1)) * R;
+            if constexpr (NW % 2 == 0) {        // 8-byte accesses (records are 8-byte aligned for even NW)
+                typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
+                lds_v2* rec = (lds_v2*)(pool + r);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) A[w] = live ? pool[r + w] : 0u;
-            base = pool[r + NW]; mlo = pool[r + NW + 1]; mhi = pool[r + NW + 2]; t = (int32_t)pool[r + NW + 3];
+                for (int w = 0; w < NW; w += 2) { const bsx_u32x2 v = rec[w / 2]; A[w] = live ? v.x : 0u; A[w + 1] = live ? v.y : 0u; }
+                const bsx_u32x2 b0 = rec[NW / 2], b1 = rec[NW / 2 + 1];
+                base = b0.x; mlo = b0.y; mhi = b1.x; t = (int32_t)b1.y;
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) A[w] = live ? pool[r + w] : 0u;
+                base = pool[r + NW]; mlo = pool[r + NW + 1]; mhi = pool[r + NW + 2]; t = (int32_t)pool[r + NW + 3];
+            }
             head = (head + n) & (kPoolCap - 1);
             count -= n;
         } else {
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
                 n_capfail += found ? 0u : m;
                 extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
             } else {
-                const uint32_t wl = m * traj, wsq = wl * traj;
+                const uint32_t wl = __umul24(m, traj), wsq = wl * traj;   // m <= 64, traj < 2^14
                 bool in_regs = false;
 #pragma unroll
                 for (int j = 0; j < kTagAcc; ++j) {
@@ -251,7 +260,9 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
 
         // ---- merge lanes of one group that are in the same state (same group = same time)
         {
-            const uint32_t slot = (((hfull ^ (base * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 24);
+            // (sibling states differ in a few bits: the slot needs a mixing hash; 24-bit multiplies are full rate)
+            const uint32_t hx = hfull ^ (hfull >> 15) ^ (base >> 6);
+            const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kMergeSlots - 1);
             if (cand) dd_ids[slot] = (uint8_t)lane;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -283,9 +294,19 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
         if (cand) {
             const uint32_t rank = __popcll(keepers & ((1ull << lane) - 1ull));
             const uint32_t r = ((head + count + rank) & (kPoolCap - 1)) * R;
+            if constexpr (NW % 2 == 0) {
+                typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
+                lds_v2* rec = (lds_v2*)(pool + r);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) pool[r + w] = A[w];
-            pool[r + NW] = base; pool[r + NW + 1] = mlo; pool[r + NW + 2] = mhi; pool[r + NW + 3] = (uint32_t)t;
+                for (int w = 0; w < NW; w += 2) { bsx_u32x2 v; v.x = A[w]; v.y = A[w + 1]; rec[w / 2] = v; }
+                bsx_u32x2 b0, b1;
+                b0.x = base; b0.y = mlo; b1.x = mhi; b1.y = (uint32_t)t;
+                rec[NW / 2] = b0; rec[NW / 2 + 1] = b1;
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) pool[r + w] = A[w];
+                pool[r + NW] = base; pool[r + NW + 1] = mlo; pool[r + NW + 2] = mhi; pool[r + NW + 3] = (uint32_t)t;
+            }
         }
         count += (uint32_t)__popcll(keepers);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

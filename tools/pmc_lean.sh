@@ -14,7 +14,7 @@ import sys, glob, csv, collections
 acc = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'lean' in r['Kernel_Name']:
+        if 'pool' in r['Kernel_Name'] or 'lean' in r['Kernel_Name']:
             a = acc[r['Counter_Name']]; a[0] += 1; a[1] += float(r['Counter_Value'])
 for k, (n, v) in sorted(acc.items()):
     print('%-28s launches %d  per launch %.4g' % (k, n, v / n))
