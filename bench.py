@@ -95,7 +95,7 @@ def main():
     if comm.rank == 0:
         value = tot_ref * n / elapsed
         problems = batch * args.steps * comm.world
-        # roofline of the dominant kernel (k_attract_lean), rank 0: algorithmic bytes per launch / avg duration
+        # roofline of the dominant kernel (k_attract_pool), rank 0: algorithmic bytes per launch / avg duration
         avg_launch_s = kernel_ms / 1e3 / launches
         alg_bytes_per_launch = steps_ref / launches * n * BYTES_PER_NODE_UPDATE
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9
@@ -129,7 +129,7 @@ def main():
             'n_attractors': n_attractors,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_attract_lean<NW=2,K=2,LDS>', 'avg_launch_ms': avg_launch_s * 1e3,
+                         'kernel': 'k_attract_pool<NW=2,K=2,LDS>', 'avg_launch_ms': avg_launch_s * 1e3,
                          'alg_bytes_per_launch': alg_bytes_per_launch},
         }
         if comm.world == 1 and not args.no_cpu_baseline:
