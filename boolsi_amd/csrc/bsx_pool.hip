@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
 #endif
 
     // is `s` a cached cycle state?  -> the entry's tag word (0 = no); `hfull` = the state's hash
+    uint32_t hit_len = 0;                   // NW <= 2: the entry's length word comes with the probe's 16-byte read
     auto probe = [&](const uint32_t (&s)[NW], uint32_t& hfull) -> uint32_t {
         hfull = hash_state<NW>(s);
         uint32_t h = hfull & cmask;
@@ -111,12 +112,11 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
         uint32_t et, d;
         if constexpr (NW == 1) {
             uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-            asm volatile("" : "+v"(v.z), "+v"(v.w));
-            d = v.x ^ s[0]; et = v.y;
+            asm volatile("" : "+v"(v.w));
+            d = v.x ^ s[0]; et = v.y; hit_len = v.z;
         } else if constexpr (NW == 2) {
             uint4 v = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(e, 16));
-            asm volatile("" : "+v"(v.w));
-            d = (v.x ^ s[0]) | (v.y ^ s[1]); et = v.z;
+            d = (v.x ^ s[0]) | (v.y ^ s[1]); et = v.z; hit_len = v.w;
         } else {
             d = 0;
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
                 for (int w = 0; w < NW; ++w) d2 |= f[w] ^ s[w];
                 const uint32_t ft = f[NW];
                 const bool here = (d2 == 0) & (ft != 0);
-                if (here) { hit = true; et = ft; }
+                if (here) { hit = true; et = ft; hit_len = f[NW + 1]; }
                 walking = (ft >> 31) != 0 && !here;
             }
         }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
         const uint32_t m = (uint32_t)(__popc(mlo) + __popc(mhi));
         if (live && res != 0) {
             const uint32_t tg = res & kTagMask, mu = (uint32_t)t, traj = tp + mu;
-            const uint32_t lam = lamtab[tg - 1];
+            const uint32_t lam = NW <= 2 ? hit_len : lamtab[tg - 1];
             const bool found = mu <= cap_rel && lam <= cap_rel - mu;
             const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
             if (P.per_problem) {
