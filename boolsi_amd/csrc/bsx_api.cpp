@@ -85,6 +85,8 @@ struct bsx_engine {
     bool pool_ok = false;       // the class-pool kernel fits the LDS for this network
     size_t cache_stride = 0;    // bytes per slot of the LDS cache mirror
     std::vector<CycleRecord> h_journal;
+    bool journal_stale = true;  // a general-kernel pass (the only writer of the journal) ran since h_journal was read
+    uint32_t mirror_slots = 64;
     uint32_t fast_steps = 0;    // lean kernel: steps without a cached cycle state before a problem is handed over (0 = default)
     bool fast_calibrated = false;
     uint32_t cache_lds_slots = 0;
@@ -416,6 +418,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     h->fast_ok = true;
     h->h_journal.clear();
+    h->journal_stale = true;
     h->fast_steps = 0;
     h->fast_calibrated = false;
     sp.n_any = n_any;
@@ -520,13 +523,12 @@ enum PassKind { kPassGeneral = 0, kPassLean = 1, kPassPool = 2 };
 // to hold what the journal holds (4 slots per state keeps probe chains short); a smaller mirror leaves
 // the LDS to more workgroups.  The general kernel inserts while it runs and keeps the full size.
 int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
+    if (!h->journal_stale) { *slots_out = h->mirror_slots; return BSX_OK; }
     unsigned int known = 0;
     HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
     known = std::min<unsigned int>(known, kCycleJournalCap);
-    if (h->h_journal.size() != known) {
-        h->h_journal.resize(known);
-        if (known) HIPCHK(h, hipMemcpy(h->h_journal.data(), h->d_cc_journal.p, known * sizeof(CycleRecord), hipMemcpyDeviceToHost));
-    }
+    h->h_journal.resize(known);
+    if (known) HIPCHK(h, hipMemcpy(h->h_journal.data(), h->d_cc_journal.p, known * sizeof(CycleRecord), hipMemcpyDeviceToHost));
     uint64_t states = 0;
     uint32_t taken = 0;
     for (const CycleRecord& r : h->h_journal) {
@@ -537,13 +539,15 @@ int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
     }
     uint32_t slots = 64;
     while (slots < 4 * states && slots < h->cache_lds_slots) slots *= 2;
-    *slots_out = std::min(slots, h->cache_lds_slots);
+    h->mirror_slots = *slots_out = std::min(slots, h->cache_lds_slots);
+    h->journal_stale = false;
     return BSX_OK;
 }
 
 int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>& d_log, MergedTable* merged,
                         AttractRun& run) {
     const bool fast = kind != kPassGeneral;
+    if (!fast) h->journal_stale = true;         // the detector may publish attractors
     size_t shmem = h->shmem_attract;
     if (fast) {
         uint32_t slots = h->cache_lds_slots;
