@@ -142,7 +142,10 @@ class Engine:
 
     # -- runs ---------------------------------------------------------------------------------
     def attract(self, first, count, max_t=inf, max_len=inf, per_problem=False, cap=65536):
-        table = np.zeros(cap, _lib.ATTR_REC)
+        # the output table is reused between calls (the library fills table[0..n_out), which is copied out)
+        table = getattr(self, '_attr_table', None)
+        if table is None or len(table) < cap:
+            table = self._attr_table = np.zeros(cap, _lib.ATTR_REC)
         pp = np.zeros(count, _lib.PROBLEM_REC) if per_problem else None
         n_out = C.c_uint32()
         none = C.c_uint64()
