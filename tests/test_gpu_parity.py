@@ -331,6 +331,37 @@ def test_scattered_any_nodes_take_the_lean_path(eng):
     assert np.array_equal(hits['offset'], want) and np.array_equal(hits['t'], ref['t_stop'][want])
 
 
+def _table(rows, key_fn):
+    return sorted((key_fn(a['key']), int(a['length']), int(a['count']), int(a['sum_l']), int(a['sum_l2_lo'])) for a in rows)
+
+
+@pytest.mark.parametrize('seed', range(32))
+def test_random_networks_aggregate_tables(eng, seed):
+    """The production call (no per-problem records) on random networks: ordered and chaotic rules, scattered
+    'any' nodes, constant fixed nodes, origin perturbations; ranges that are no multiples of the 64-problem
+    groups of the pool kernel.  Tables, no-attractor counts and reference step counts must equal the oracle's."""
+    from oracle.cpu_oracle import key_int as okey
+    rng = random.Random(9000 + seed)
+    n = rng.choice([12, 20, 31, 32, 40, 64, 64, 70, 100])
+    k = rng.choice([1, 2, 2, 2, 3])
+    n_any = min(n, rng.randint(14, 22))
+    any_nodes = set(rng.sample(range(n), n_any)) if seed % 3 else set(range(n_any))
+    bits = synth.seeded_bits(n, 500 + seed)
+    fixed = {i: str(rng.getrandbits(1)) for i in rng.sample(range(n), rng.randint(0, 3))} if seed % 2 else None
+    pert = {rng.randrange(n): {str(rng.getrandbits(1)): '2, 4'}} if seed % 4 == 1 else None
+    text = synth.network_yaml(n, k, 7000 + seed, initial={i: str(bits[i]) for i in range(n) if i not in any_nodes},
+                              fixed=fixed, perturbations=pert)
+    max_t = rng.choice([math.inf, 300, 40])
+    cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, max_t)
+    total = space.n_problems
+    for first, count in ((0, min(total, (1 << 14) + 37)), (max(0, total - 30011), min(total, 30011))):
+        for _ in range(2):          # second pass: whatever the cache learnt is in use
+            r = eng.attract(first, count, t_of(None if max_t is math.inf else max_t))
+            pp, table, none, steps = orc.attract(first, count, None if max_t is math.inf else max_t, None, True, n_threads=8)
+            assert _table(r.table, key_int) == _table(table, okey)
+            assert r.n_no_attractor == none and r.stats['state_steps'] == steps
+
+
 def test_attract_with_fixed_node_variations_uses_detector_only(eng):
     # not reachable through the YAML front end (attract forbids variations) but allowed by the C-ABI:
     # cycles differ per fixed-node variant, so the cycle cache must stay out of it
