@@ -335,7 +335,7 @@ def _table(rows, key_fn):
     return sorted((key_fn(a['key']), int(a['length']), int(a['count']), int(a['sum_l']), int(a['sum_l2_lo'])) for a in rows)
 
 
-@pytest.mark.parametrize('seed', range(32))
+@pytest.mark.parametrize('seed', range(20))
 def test_random_networks_aggregate_tables(eng, seed):
     """The production call (no per-problem records) on random networks: ordered and chaotic rules, scattered
     'any' nodes, constant fixed nodes, origin perturbations; ranges that are no multiples of the 64-problem
