@@ -20,7 +20,7 @@ namespace bsx {
 //
 // Each wave keeps its classes in a ring buffer in LDS (the pool) and runs one of two stages per
 // iteration, all 64 lanes doing one network update either way:
-//   fresh stage: the next 64 consecutive problems -- init, lookup of s(T_p) itself, update, lookup;
+//   fresh stage: the next 64 consecutive problems -- init, update, lookup (s(T_p) itself is looked up only when s(T_p + 1) is a cycle state);
 //   pool stage (when the pool holds at least 64 classes, or the input is used up): the 64 oldest
 //                classes -- update, lookup.
 // After the lookup: resolved lanes are accumulated, lanes past the FAST length go to the straggler list
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
             mhi = lane < 32u ? 0u : 1u << (lane - 32u);
             t = -(int32_t)tp;
             q.next += n;
-            if (!has_warmup) res = live ? probe(A, hfull) : 0u;      // s(T_p) = s(0) itself may be a cycle state: mu = 0
 #ifdef BSX_DIAG
             ++dbg_fresh;
 #endif
@@ -202,6 +201,16 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
             }
             uint32_t et = probe(nxt, hfull);
             if (has_warmup) et = t >= 0 ? et : 0u;          // states before T_p do not count
+            // s(T_p) = s(0) itself may be a cycle state (mu = 0).  It is only looked up when s(1) is one --
+            // a successor of a cycle state is a cycle state -- instead of for every fresh problem.
+            if (!has_warmup && __ballot(et != 0 && t == 1)) {
+                if (et != 0 && t == 1) {
+                    uint32_t h0;
+                    const uint32_t len1 = hit_len;
+                    const uint32_t et0 = probe(A, h0);
+                    if (et0) { et = et0; t = 0; } else hit_len = len1;
+                }
+            }
 #pragma unroll
             for (int w = 0; w < NW; ++w) A[w] = nxt[w];
             res = et;
