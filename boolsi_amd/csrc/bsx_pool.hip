@@ -216,6 +216,17 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
             res = et;
         }
 
+        // ---- candidates for the merge post their lane id now; the slot is read back right away and used
+        //      after the resolve block, whose arithmetic hides the two LDS round trips
+        bool cand = live && res == 0 && t < fast_steps;
+        // (sibling states differ in a few bits: the slot needs a mixing hash; 24-bit multiplies are full rate)
+        const uint32_t hx = hfull ^ (hfull >> 15) ^ (base >> 6);
+        const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kMergeSlots - 1);
+        if (cand) dd_ids[slot] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t w = cand ? (uint32_t)dd_ids[slot] : lane;
+
         // ---- resolved classes: every member has mu = t
         const uint32_t m = (uint32_t)(__popc(mlo) + __popc(mhi));
         if (live && res != 0) {
@@ -258,24 +269,15 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
             }
         }
         // ---- classes past the FAST length go back as (group base, member mask)
-        bool cand = live && res == 0;
-        if (cand && t >= fast_steps) {
+        if (live && res == 0 && t >= fast_steps) {
             atomicAdd(&P.ctr->n_stragglers, (unsigned long long)m);
             const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
             if (3 * at + 2 < P.stragglers_cap) { P.stragglers[3 * at] = base; P.stragglers[3 * at + 1] = mlo; P.stragglers[3 * at + 2] = mhi; }
             else atomicOr(&P.ctr->straggler_overflow, 1u);
-            cand = false;
         }
 
         // ---- merge lanes of one group that are in the same state (same group = same time)
         {
-            // (sibling states differ in a few bits: the slot needs a mixing hash; 24-bit multiplies are full rate)
-            const uint32_t hx = hfull ^ (hfull >> 15) ^ (base >> 6);
-            const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kMergeSlots - 1);
-            if (cand) dd_ids[slot] = (uint8_t)lane;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t w = cand ? (uint32_t)dd_ids[slot] : lane;
             // every lane takes part in the permutes (a lane masked off would deliver nothing to its readers)
             uint32_t differ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)base) ^ base;
             differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)(cand ? 0u : 1u));
