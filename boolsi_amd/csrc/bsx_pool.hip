@@ -92,9 +92,6 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
 
     const uint32_t cap_rel = (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)(P.max_t - tp);
 
-    uint32_t tcnt[kTagAcc], tsl[kTagAcc], tsl2[kTagAcc];
-#pragma unroll
-    for (int j = 0; j < kTagAcc; ++j) tcnt[j] = tsl[j] = tsl2[j] = 0;
     unsigned long long extra_ref = 0;
     uint32_t nexec = 0, n_none = 0, n_capfail = 0;
     WaveQueue q{0, 0, true};
@@ -251,21 +248,13 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
                 n_capfail += found ? 0u : m;
                 extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
             } else {
-                const uint32_t wl = __umul24(m, traj), wsq = wl * traj;   // m <= 64, traj < 2^14
-                bool in_regs = false;
-#pragma unroll
-                for (int j = 0; j < kTagAcc; ++j) {
-                    const bool here = tg == (uint32_t)(j + 1) && tsl2[j] < 0x7FFF0000u;
-                    tcnt[j] += here ? m : 0u;
-                    tsl[j] += here ? wl : 0u;
-                    tsl2[j] += here ? wsq : 0u;
-                    in_regs = in_regs || here;
-                }
-                if (!in_regs) {
-                    atomicAdd(&acc_cnt[tg - 1], m);
-                    atomicAdd(&acc_sl[tg - 1], (unsigned long long)wl);
-                    atomicAdd(&acc_sl2[tg - 1], (unsigned long long)wsq);
-                }
+                // Straight into the workgroup's accumulators: a wave resolves less than one class per
+                // iteration on average (64 problems end as one or two classes), so the LDS atomics do not
+                // queue up, and no per-lane sums have to be carried in registers.
+                const uint32_t wl = __umul24(m, traj);      // m <= 64, traj < 2^14
+                atomicAdd(&acc_cnt[tg - 1], m);
+                atomicAdd(&acc_sl[tg - 1], (unsigned long long)wl);
+                atomicAdd(&acc_sl2[tg - 1], (unsigned long long)wl * traj);
             }
         }
         // ---- classes past the FAST length go back as (group base, member mask)
@@ -324,15 +313,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- epilogue: per-lane sums -> workgroup accumulators -> one log record per attractor and workgroup
-#pragma unroll
-    for (int j = 0; j < kTagAcc; ++j) {
-        if (tcnt[j]) {
-            atomicAdd(&acc_cnt[j], tcnt[j]);
-            atomicAdd(&acc_sl[j], (unsigned long long)tsl[j]);
-            atomicAdd(&acc_sl2[j], (unsigned long long)tsl2[j]);
-        }
-    }
+    // ---- epilogue: workgroup accumulators -> one log record per attractor and workgroup
     __syncthreads();
     for (uint32_t a = threadIdx.x; a < kAccs; a += blockDim.x) {
         const uint32_t cn = acc_cnt[a];
