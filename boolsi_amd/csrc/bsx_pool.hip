@@ -28,14 +28,20 @@ namespace bsx {
 // their masks: per-wave hash slots + ds_bpermute compare, as in the lean kernel) and the survivors are
 // appended to the pool.  Nothing but the accumulators lives in registers across iterations, so there is
 // no per-lane state machine and no service round.
-constexpr uint32_t kPoolCap = 128;              // classes per wave (ring buffer, power of two)
+// Workgroup = 12 waves sharing one LUT and cache mirror: with n = 64 that is 39 KiB + 12 x 3.3 KiB of LDS,
+// so two workgroups fit a CU = 6 waves per SIMD, 3 from each (with 8-wave workgroups and 128-class rings
+// it was 4).  The kernel is bound by the latency of its dependent LDS round trips, so waves matter.
+constexpr int kPoolBlock = 768;
+constexpr int kPoolWaves = kPoolBlock / 64;
+constexpr uint32_t kPoolCap = 112;              // classes per wave (ring buffer; > 64 + what a fresh stage leaves)
 constexpr uint32_t kPoolGroup = 64;             // problems loaded together = lanes
+constexpr uint32_t kPoolSlots = 128;            // merge slots per wave (one-byte lane ids)
 
 constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // state, group base, members lo/hi, time
-constexpr int pool_min_waves(int nw) { return nw <= 2 ? 4 : 2; }
+constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
 
 template <int NW, int K, int LM>
-__global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(const AttractParams P) {
+__global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
     const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
     unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl + kAccs);
     uint32_t* lamtab = acc_cnt + kAccs;
     uint32_t* keytab = lamtab + kAccs;
-    constexpr uint32_t kWaveWords = kPoolCap * R + 128 + kMergeSlots / 4;
+    constexpr uint32_t kWaveWords = kPoolCap * R + 128 + kPoolSlots / 4;
     uint32_t* wave_base = keytab + ((kAccs * NW + 1u) & ~1u) + wave * kWaveWords;
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
@@ -151,7 +157,9 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
             // ---- pool stage: the oldest classes (their states were looked up when they were stored)
             const uint32_t n = count < 64u ? count : 64u;
             live = lane < n;
-            const uint32_t r = ((head + lane) & (kPoolCap - 1)) * R;
+            uint32_t ri = head + lane;
+            ri -= ri >= kPoolCap ? kPoolCap : 0u;
+            const uint32_t r = ri * R;
             if constexpr (NW % 2 == 0) {        // 8-byte accesses (records are 8-byte aligned for even NW)
                 typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
                 lds_v2* rec = (lds_v2*)(pool + r);
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
                 for (int w = 0; w < NW; ++w) A[w] = live ? pool[r + w] : 0u;
                 base = pool[r + NW]; mlo = pool[r + NW + 1]; mhi = pool[r + NW + 2]; t = (int32_t)pool[r + NW + 3];
             }
-            head = (head + n) & (kPoolCap - 1);
+            head += n;
+            head -= head >= kPoolCap ? kPoolCap : 0u;
             count -= n;
         } else {
             // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
         bool cand = live && res == 0 && t < fast_steps;
         // (sibling states differ in a few bits: the slot needs a mixing hash; 24-bit multiplies are full rate)
         const uint32_t hx = hfull ^ (hfull >> 15) ^ (base >> 6);
-        const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kMergeSlots - 1);
+        const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kPoolSlots - 1);
         if (cand) dd_ids[slot] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -293,7 +302,11 @@ __global__ __launch_bounds__(kBlock, pool_min_waves(NW)) void k_attract_pool(con
         const uint64_t keepers = __ballot(cand);
         if (cand) {
             const uint32_t rank = __popcll(keepers & ((1ull << lane) - 1ull));
-            const uint32_t r = ((head + count + rank) & (kPoolCap - 1)) * R;
+            uint32_t tail = head + count;                   // uniform; head < cap, count <= cap
+            tail -= tail >= kPoolCap ? kPoolCap : 0u;
+            uint32_t ri = tail + rank;
+            ri -= ri >= kPoolCap ? kPoolCap : 0u;
+            const uint32_t r = ri * R;
             if constexpr (NW % 2 == 0) {
                 typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
                 lds_v2* rec = (lds_v2*)(pool + r);
@@ -339,7 +352,7 @@ static hipError_t launch_pool_nk(int lut_mode, dim3 grid, size_t shmem, hipStrea
     BSX_KERNEL_FOR_MODE(k_attract_pool, NW, K, lut_mode, fn);
     if (!fn) return hipErrorInvalidValue;
     void* args[] = {const_cast<AttractParams*>(&P)};
-    return hipLaunchKernel(fn, grid, dim3(kBlock), args, shmem, st);
+    return hipLaunchKernel(fn, grid, dim3(kPoolBlock), args, shmem, st);
 }
 template <int NW, int K>
 static hipError_t configure_pool_nk(int lut_mode, dim3, size_t shmem, hipStream_t, int& blocks_per_cu) {
@@ -348,7 +361,7 @@ static hipError_t configure_pool_nk(int lut_mode, dim3, size_t shmem, hipStream_
     if (!fn) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, shmem);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kPoolBlock, shmem);
 }
 
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
@@ -364,8 +377,8 @@ hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int
 // bytes of LDS behind the cache mirror: per-attractor tables + per-wave pool, accumulators and id slots
 size_t pool_extra_bytes(uint32_t nw) {
     const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16;
-    const size_t per_wave = ((size_t)kPoolCap * pool_rec_words(nw) + 128 + kMergeSlots / 4) * 4;
-    return tables + (size_t)kWavesPerBlock * per_wave;
+    const size_t per_wave = ((size_t)kPoolCap * pool_rec_words(nw) + 128 + kPoolSlots / 4) * 4;
+    return tables + (size_t)kPoolWaves * per_wave;
 }
 
 }  // namespace bsx
