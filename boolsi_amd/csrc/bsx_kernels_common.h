@@ -93,7 +93,7 @@ constexpr int kLutLdsNibble = 2;    // one entry per 4 state bits, in LDS: 16x s
 template <int NW, int K, int LM = kLutGlobal>
 struct NetView {
     static constexpr bool LDS = LM != kLutGlobal;
-    static constexpr bool kMasksInRegs = (K <= 3);
+    static constexpr bool kMasksInRegs = (K <= 3) || (K == 4 && NW == 1);     // up to 16 registers beyond K = 3
     // LDS = true: the gather LUT sits in LDS right behind the masks, and the kernel's dynamic LDS starts
     // at LDS address 0 (checked by stage_network), so an entry's address is a compile-time constant plus
     // the scaled byte -- no base-pointer add per lookup.
