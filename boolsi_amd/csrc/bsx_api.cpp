@@ -709,19 +709,35 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     const bool merge_lanes = merge_mode != 0;
     while (use_fast && h->fast_ok && done < count) {
         const uint64_t tile = std::min<uint64_t>(count - done, h->fast_calibrated ? kLeanTile : kProbeTile);
+        // straggler list: one word per problem, or up to three per class (base + 64-bit member mask) from the
+        // pool kernel -- probe tiles get room for every problem as a class of its own, big tiles for a third
+        // (more stragglers than that and the lean path is the wrong tool anyway)
+        const uint64_t strag_cap = h->fast_calibrated ? tile : 3 * tile;
         DevBuf<uint32_t>& d_strag = h->d_strag;
-        if (d_strag.n < tile) HIPCHK(h, d_strag.alloc(tile));
+        if (d_strag.n < strag_cap) HIPCHK(h, d_strag.alloc(strag_cap));
         AttractParams Q = P;
         advance_first(Q.sp, first, done);
         Q.count = tile;
         Q.fast_steps = h->fast_steps;
-        Q.merge = merge_lanes ? 1u : 0u;
+        // the pool kernel first runs with member counts (classes of different groups merge too); that only works
+        // while nothing has to go back to the general kernel, so a tile that raises the abort flag is repeated
+        // with member masks.  Per-problem records need the masks from the start.
+        bool counting = merge_mode == 2 && !per_problem && (h->fast_calibrated || std::getenv("BSX_FORCE_COUNTING"));     // (knob: tests)
+        Q.merge = counting ? 2u : (merge_lanes ? 1u : 0u);
         Q.per_problem = per_problem ? d_pp.p + done : nullptr;
         Q.stragglers = d_strag.p;
-        Q.stragglers_cap = tile;
+        Q.stragglers_cap = strag_cap;
         AttractRun r;
         MergedTable tile_table;         // folded into `merged` only if the pass is accepted
         if (int rc = launch_attract_pass(h, Q, merge_mode == 2 ? kPassPool : kPassLean, d_log, &tile_table, r)) return rc;
+        if (counting && (r.ctr.straggler_overflow & 2u)) {
+            kernel_ms += r.ms; ++launches;              // dropped pass
+            counting = false;
+            Q.merge = 1u;
+            tile_table.clear();
+            r = AttractRun{};
+            if (int rc = launch_attract_pass(h, Q, kPassPool, d_log, &tile_table, r)) return rc;
+        }
         if (r.ctr.straggler_overflow) {
             // more (group, mask) pairs than the list holds: the cache does not cover this space.  Drop the
             // pass and give the rest of the range to the detector.
@@ -770,6 +786,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         }
         done += tile;
         const bool many = r.ctr.n_stragglers > tile / 32;
+        if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] tile %llu: %llu stragglers, %llu of them ended on a cached cycle state; FAST length %u\n", (unsigned long long)tile, (unsigned long long)r.ctr.n_stragglers, (unsigned long long)late, h->fast_steps);
         if (many && 2 * late >= r.ctr.n_stragglers && h->fast_steps < kFastStepsMax) {
             h->fast_steps = std::min(kFastStepsMax, h->fast_steps * 4);     // long transients: give FAST more steps
         } else {

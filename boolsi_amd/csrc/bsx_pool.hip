@@ -48,6 +48,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
     const bool has_warmup = tp != 0;
+    // P.merge == 2: classes carry a member COUNT instead of the member mask, so classes of different groups
+    // may merge too (same state, same time); a class that would have to go back to the general kernel cannot
+    // be taken apart again, so it raises the abort flag and the host repeats the tile with member masks.
+    const bool counting = P.merge == 2;                     // uniform
     const int32_t fast_steps = (int32_t)P.fast_steps;
     const uint32_t cmask = P.cc.lds_slots - 1;
     constexpr int S = CacheLayout<NW>::kStride;
@@ -187,8 +191,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             live = lane < n;
             base = (uint32_t)q.next;
             init_problem_simple<NW>(P.sp, q.next + lane, A);
-            mlo = lane < 32u ? 1u << lane : 0u;
-            mhi = lane < 32u ? 0u : 1u << (lane - 32u);
+            mlo = counting ? 1u : (lane < 32u ? 1u << lane : 0u);
+            mhi = counting || lane < 32u ? 0u : 1u << (lane - 32u);
             t = -(int32_t)tp;
             q.next += n;
 #ifdef BSX_DIAG
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         //      after the resolve block, whose arithmetic hides the two LDS round trips
         bool cand = live && res == 0 && t < fast_steps;
         // (sibling states differ in a few bits: the slot needs a mixing hash; 24-bit multiplies are full rate)
-        const uint32_t hx = hfull ^ (hfull >> 15) ^ (base >> 6);
+        const uint32_t hx = hfull ^ (hfull >> 15) ^ (counting ? (uint32_t)t : base >> 6);
         const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kPoolSlots - 1);
         if (cand) dd_ids[slot] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         const uint32_t w = cand ? (uint32_t)dd_ids[slot] : lane;
 
         // ---- resolved classes: every member has mu = t
-        const uint32_t m = (uint32_t)(__popc(mlo) + __popc(mhi));
+        const uint32_t m = counting ? mlo : (uint32_t)(__popc(mlo) + __popc(mhi));
         if (live && res != 0) {
             const uint32_t tg = res & kTagMask, mu = (uint32_t)t, traj = tp + mu;
             const uint32_t lam = NW <= 2 ? hit_len : lamtab[tg - 1];
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         }
         // ---- classes past the FAST length go back as (group base, member mask)
         if (live && res == 0 && t >= fast_steps) {
+            if (counting) atomicOr(&P.ctr->straggler_overflow, 2u);         // members unknown: the host repeats the tile
             atomicAdd(&P.ctr->n_stragglers, (unsigned long long)m);
             const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
             if (3 * at + 2 < P.stragglers_cap) { P.stragglers[3 * at] = base; P.stragglers[3 * at + 1] = mlo; P.stragglers[3 * at + 2] = mhi; }
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         // ---- merge lanes of one group that are in the same state (same group = same time)
         {
             // every lane takes part in the permutes (a lane masked off would deliver nothing to its readers)
-            uint32_t differ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)base) ^ base;
+            uint32_t differ = counting ? 0u : (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)base) ^ base;
             differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)(cand ? 0u : 1u));
             differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), t) ^ (uint32_t)t;      // (same group = same time in a FIFO pool; checked anyway)
 #pragma unroll
@@ -285,15 +290,23 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             const bool same = cand & (w != lane) & (differ == 0u);
             if (__ballot(same)) {
                 if (same) {
-                    if (mlo) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
-                    if (mhi) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w + 1], mhi);
+                    if (counting) {
+                        atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
+                    } else {
+                        if (mlo) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
+                        if (mhi) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w + 1], mhi);
+                    }
                     cand = false;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (cand) {
                     const uint32_t glo = dd_acc[2 * lane], ghi = dd_acc[2 * lane + 1];
-                    if (glo | ghi) { mlo |= glo; mhi |= ghi; dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0; }
+                    if (glo | ghi) {
+                        mlo = counting ? mlo + glo : mlo | glo;
+                        mhi |= ghi;
+                        dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
+                    }
                 }
             }
         }

@@ -282,6 +282,42 @@ def test_lean_kernel_stragglers_and_fallback(eng):
     _same_attract(eng, orc, (1 << 20), 1 << 14, 30, 1)
 
 
+def test_counting_pass_aborts_and_is_repeated(eng):
+    """A counting pass (member counts, no masks) that meets classes it cannot resolve is dropped and the
+    tile repeated with member masks; forced here on a space with far more attractors than the mirror holds."""
+    from oracle.cpu_oracle import key_int as okey
+    cfg, net, space, orc = _setup(eng, _identity_yaml(14, period2=[(2, 11)]), Mode.ATTRACT, math.inf)
+    os.environ['BSX_FORCE_COUNTING'] = '1'
+    try:
+        for first, count in ((0, 1 << 14), (100, 12000)):
+            r = eng.attract(first, count)
+            pp, table, none, steps = orc.attract(first, count, None, None, True, n_threads=8)
+            assert _table(r.table, key_int) == _table(table, okey)
+            assert r.n_no_attractor == none and r.stats['state_steps'] == steps
+            if first == 0 and eng.cycle_cache and os.environ.get('BSX_MERGE', '2') == '2':
+                # discovery sample, counting pass, repeat with masks, detector on the stragglers (after that the
+                # space is marked as not covered by the cache and the detector serves it alone)
+                assert r.stats['kernel_launches'] >= 4
+    finally:
+        os.environ.pop('BSX_FORCE_COUNTING')
+
+
+def test_long_transients_raise_the_fast_length(eng):
+    """Production call (no per-problem records) on a network whose transients outlast the FAST length: the
+    first probe tile comes back as stragglers that all end on a cached cycle state, the FAST length is raised,
+    and later calls are resolved by the pool kernel alone.  Tables must equal the oracle's throughout."""
+    from oracle.cpu_oracle import key_int as okey
+    cfg, net, space, orc = _setup(eng, _chain_yaml(), Mode.ATTRACT, math.inf)
+    for first, count in ((0, 1 << 16),                       # short transients: calibrates the lean path
+                         ((1 << 48) - 58982, 1 << 16),       # ~10 % of the problems need more than 48 steps
+                         ((1 << 56) - 40000, 1 << 16),       # again, after the FAST length has been raised
+                         ((1 << 40), 1 << 15)):
+        r = eng.attract(first, count)
+        pp, table, none, steps = orc.attract(first, count, None, None, True, n_threads=8)
+        assert _table(r.table, key_int) == _table(table, okey)
+        assert r.n_no_attractor == none and r.stats['state_steps'] == steps
+
+
 def _identity_yaml(n, period2=()):
     """x_i' = x_i (every state a fixed point), except the pairs in `period2`, which swap (cycles of length 2)."""
     rule = {i: i for i in range(n)}
