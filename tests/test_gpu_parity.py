@@ -371,7 +371,7 @@ def _table(rows, key_fn):
     return sorted((key_fn(a['key']), int(a['length']), int(a['count']), int(a['sum_l']), int(a['sum_l2_lo'])) for a in rows)
 
 
-@pytest.mark.parametrize('seed', range(20))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BSX_FUZZ_SEEDS', '20'))))
 def test_random_networks_aggregate_tables(eng, seed):
     """The production call (no per-problem records) on random networks: ordered and chaotic rules, scattered
     'any' nodes, constant fixed nodes, origin perturbations; ranges that are no multiples of the 64-problem
@@ -387,7 +387,9 @@ def test_random_networks_aggregate_tables(eng, seed):
     pert = {rng.randrange(n): {str(rng.getrandbits(1)): '2, 4'}} if seed % 4 == 1 else None
     text = synth.network_yaml(n, k, 7000 + seed, initial={i: str(bits[i]) for i in range(n) if i not in any_nodes},
                               fixed=fixed, perturbations=pert)
-    max_t = rng.choice([math.inf, 300, 40])
+    # no time cap only where cycles are sure to be short (a chaotic network can have astronomically long ones:
+    # the reference, the oracle and the detector would all run until their step limits)
+    max_t = rng.choice([math.inf, 300, 40]) if (k == 1 or (k == 2 and n <= 40)) else rng.choice([300, 40])
     cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, max_t)
     total = space.n_problems
     for first, count in ((0, min(total, (1 << 14) + 37)), (max(0, total - 30011), min(total, 30011))):
