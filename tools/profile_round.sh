@@ -8,7 +8,7 @@ TAG=${1:-round}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-python3 bench.py --cpu-log2-sample 25 > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
