@@ -53,7 +53,8 @@ def main():
         raise SystemExit('--gpus {} but WORLD_SIZE is {}: launch N > 1 through torch.distributed.run'.format(
             args.gpus, comm.world))
     from boolsi_amd.engine import Engine
-    eng = Engine(comm.local_rank)
+    # BSX_BENCH_DEVICE: rehearse several ranks on one GPU (with BSX_DIST_BACKEND=gloo); normally rank = GPU
+    eng = Engine(int(os.environ.get('BSX_BENCH_DEVICE', comm.local_rank)))
 
     cfg = parse_input_text(synth.north_star_yaml(), MAX_T, Mode.ATTRACT)
     net, space = compile_problem(cfg)
