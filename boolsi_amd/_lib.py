@@ -20,7 +20,9 @@ EXPORTS = (
     'bsx_create', 'bsx_destroy', 'bsx_last_error', 'bsx_status_string', 'bsx_device_info',
     'bsx_set_network', 'bsx_set_problem_space', 'bsx_run_attract', 'bsx_run_target',
     'bsx_run_simulate', 'bsx_run_trajectories', 'bsx_synchronize',
+    'bsx_comm_unique_id', 'bsx_comm_init', 'bsx_comm_allgather', 'bsx_comm_destroy',
 )
+COMM_ID_BYTES = 128
 
 
 class EngineUnavailable(RuntimeError):
@@ -89,6 +91,10 @@ def load():
     lib.bsx_run_simulate.argtypes = [vp, C.POINTER(Index), u64, u64, vp, vp, vp, C.POINTER(Stats)]
     lib.bsx_run_trajectories.argtypes = [vp, C.POINTER(Index), vp, vp, u64, vp, vp, C.POINTER(Stats)]
     lib.bsx_synchronize.argtypes = [vp]
+    lib.bsx_comm_unique_id.argtypes = [vp, vp, u32]
+    lib.bsx_comm_init.argtypes = [vp, vp, u32, C.c_int, C.c_int]
+    lib.bsx_comm_allgather.argtypes = [vp, vp, u64, vp]
+    lib.bsx_comm_destroy.argtypes = [vp]
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = header and library disagree
         if name not in ('bsx_last_error', 'bsx_status_string'):

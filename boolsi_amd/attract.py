@@ -111,7 +111,7 @@ def attract_master(engine, origin_simulation_problem, simulation_problem_variati
     first, count = partition(n_simulation_problems, comm.world, comm.rank)
     merged, none, stats = run_attract_range(engine, first, count, max_t, max_attractor_l)
 
-    if comm.world > 1:
+    if comm.active:
         from . import _lib
         tables = comm.allgather_records(table_from_merged(merged, _lib.ATTR_REC))
         merged = merge_tables(tables)

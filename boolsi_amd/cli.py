@@ -5,13 +5,16 @@ option names as the reference's `boolsi` script (`boolsi/cli.py:35-63, 184-328`)
 Differences, all outside the hot path: results are kept in memory instead of a ZODB spill
 (`-d`, `-k` accepted and ignored); `-b` does not schedule anything (the GPU dequeues its own chunks),
 it only shapes the listing order under `--reference-np`; graphic outputs are not produced (`--no-pdf`
-is implied, `--print-*` warn).  Under `torch.distributed.run` every rank drives one GPU and all three
-commands range-partition the problems (boolsi_amd/dist.py); rank 0 writes the output.
+is implied, `--print-*` warn).  Started once per GPU by a launcher that sets RANK / WORLD_SIZE / MASTER_*
+(e.g. `python -m torch.distributed.run`), every rank drives one GPU and all three commands range-partition
+the problems (boolsi_amd/dist.py); rank 0 owns the output directory: it creates it, copies the input there
+and writes the results, and its path is the one every rank uses.
 `--reference-np P` lists the simulations of simulate / target in the order a reference run under
 `mpiexec -np P` (P - 1 workers, `-b` batches each) writes them (batching.BatchLayout); the default is
 the single-process order = problem-index order.
 Error policy as the reference (cli.py:138-151,181): input / engine errors are logged and the
-process terminates normally.
+process terminates normally.  In a multi-rank job a rank that fails closes its control connection, which
+ends its peers' next collective with PeerLost instead of leaving them blocked; those ranks exit with status 1.
 """
 import logging
 import os
@@ -61,8 +64,11 @@ class _Run:
     def __init__(self, kw):
         from .dist import Comm
         self.kw = kw
-        self.out = kw['output_directory']
+        self.failed = False
         self.comm = Comm.from_env()
+        # rank 0's directory is THE directory (the default name carries a per-process timestamp); it exists
+        # before any other rank goes on
+        self.out = self.comm.broadcast_obj(kw['output_directory'])
         if self.comm.rank == 0:
             configure_logging(self.out)
             log = logging.getLogger()
@@ -73,12 +79,17 @@ class _Run:
                 log.warning('Graphic output (PDF/PNG/TIFF/SVG) is not available in this build; CSV only.')
         else:
             logging.getLogger().setLevel(logging.CRITICAL)
+        self.comm.barrier()
         self.engine = None
+
+    def read_input(self, max_t, mode):
+        return process_input(self.kw['input_file'], self.out, max_t, mode, copy_input=self.comm.rank == 0)
 
     def open_engine(self):
         from .engine import Engine
         device = self.kw['device'] if self.kw['device'] is not None else self.comm.local_rank
         self.engine = Engine(device)
+        self.comm.attach_engine(self.engine)        # RCCL communicator on this engine's device
         if self.comm.rank == 0:
             logging.getLogger().info('Using GPU {}: {}.'.format(device, self.engine.device_info()['name']))
         return self.engine
@@ -86,10 +97,12 @@ class _Run:
     def finish(self):
         log = logging.getLogger()
         log.info('Terminating...')
+        self.comm.shutdown()
         if self.engine is not None:
             self.engine.close()
         log.info('All BoolSi output is located in "{}". Bye!'.format(os.path.join(os.path.abspath(self.out), '')))
-        self.comm.shutdown()
+        if self.failed and self.comm.world > 1:
+            sys.exit(1)
 
 
 def _guarded(kw, body):
@@ -104,6 +117,8 @@ def _guarded(kw, body):
         except KeyboardInterrupt:
             logging.getLogger().error('Interrupted by user.')
         except Exception as e:   # noqa: BLE001  (reference policy: log and terminate normally)
+            run.failed = True
+            run.comm.abort()     # peers blocked on this rank see the closed connection
             logging.getLogger().exception('Exception caught: {}. See stacktrace below.'.format(e))
     run.finish()
 
@@ -129,7 +144,7 @@ def simulate(**kw):
     def body(run):
         from .simulate import simulate_master
         from .output import output_simulations
-        cfg = process_input(kw['input_file'], run.out, kw['simulation_time'], Mode.SIMULATE)
+        cfg = run.read_input(kw['simulation_time'], Mode.SIMULATE)
         sims = simulate_master(run.open_engine(), cfg['origin simulation problem'],
                                cfg['simulation problem variations'], cfg['incoming node lists'],
                                cfg['truth tables'], kw['simulation_time'], cfg['total combination count'],
@@ -162,7 +177,7 @@ def attract(**kw):
         from .output import output_attractors, output_node_correlations
         max_t = kw['max_simulation_time'] or inf
         max_len = kw['max_attractor_length'] or inf
-        cfg = process_input(kw['input_file'], run.out, max_t, Mode.ATTRACT)
+        cfg = run.read_input(max_t, Mode.ATTRACT)
         if kw['no_node_correlations'] and kw['no_attractor_output']:
             logging.getLogger().info("Cannot proceed, both attractors' and node correlations' output is disabled.")
             return
@@ -201,7 +216,7 @@ def target(**kw):
         from .output import output_simulations
         max_t = kw['max_simulation_time'] or inf
         n_to_find = kw['n_simulations_reaching_target'] or inf
-        cfg = process_input(kw['input_file'], run.out, max_t, Mode.TARGET)
+        cfg = run.read_input(max_t, Mode.TARGET)
         sims = target_master(run.open_engine(), cfg['origin simulation problem'],
                              cfg['simulation problem variations'], cfg['target substate code'],
                              cfg['target node set'], cfg['incoming node lists'], cfg['truth tables'],

@@ -14,8 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "bsx.h"
-#include "bsx_device.h"
+#include "bsx_engine.h"
 
 namespace bsx {
 hipError_t launch_attract(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
@@ -38,93 +37,8 @@ hipError_t configure_simulate(int nw, int k, int lut_mode, size_t shmem);
 using namespace bsx;
 
 namespace {
-
 thread_local std::string g_create_error;
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-    hipError_t alloc(size_t count) {
-        release();
-        if (count == 0) count = 1;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    hipError_t upload(const std::vector<T>& v) {
-        hipError_t e = alloc(v.size());
-        if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-};
-
 }  // namespace
-
-struct bsx_engine {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipDeviceProp_t prop{};
-    std::string error;
-
-    // network
-    bool have_net = false;
-    uint32_t n_nodes = 0, w64 = 0;
-    DevNet net{};
-    int lut_mode = 0;           // kLutGlobal / kLutLdsByte / kLutLdsNibble (bsx_kernels_common.h)
-    size_t shmem = 0;           // masks (+ LUT) : target / simulate kernels
-    size_t shmem_attract = 0;   // + LDS mirror of the cycle-state cache
-
-    // cycle-state cache (valid for the current network + origin fixed nodes)
-    bool cache_enabled = true;
-    int lean_blocks_per_cu = 0;  // occupancy of the lean attract kernel for the current network
-    bool fast_ok = true;        // cleared when the lean kernel's straggler list overflowed for this space
-    bool pool_ok = false;       // the class-pool kernel fits the LDS for this network
-    size_t cache_stride = 0;    // bytes per slot of the LDS cache mirror
-    std::vector<CycleRecord> h_journal;
-    bool journal_stale = true;  // a general-kernel pass (the only writer of the journal) ran since h_journal was read
-    uint32_t mirror_slots = 64;
-    uint32_t fast_steps = 0;    // lean kernel: steps without a cached cycle state before a problem is handed over (0 = default)
-    bool fast_calibrated = false;
-    uint32_t cache_lds_slots = 0;
-    DevBuf<CycleRecord> d_cc_journal;
-    DevBuf<unsigned int> d_cc_claims;
-    DevBuf<unsigned int> d_cc_count;
-
-    // scratch kept across calls (grow-only): hipMalloc / hipFree per call cost ~1 ms of a 16 ms step
-    DevBuf<LogRec> d_log;
-    DevBuf<uint32_t> d_strag;
-    DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
-
-    // host copies for the bit-sliced simulate kernel's node descriptors
-    std::vector<uint32_t> h_pred_offsets, h_pred_idx;
-    std::vector<uint64_t> h_tt0;        // first table word of every node (all of it when k <= 6)
-    std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
-
-    // problem space
-    bool have_space = false;
-    DevSpace sp{};
-    DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
-
-    DevBuf<Counters> d_ctr;
-};
-
-#define HIPCHK(h, call)                                                                      \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess) {                                                              \
-            (h)->error = std::string(#call) + ": " + hipGetErrorString(e_);                  \
-            return BSX_ERR_HIP;                                                              \
-        }                                                                                    \
-    } while (0)
-
-static int fail(bsx_handle h, int status, const std::string& msg) {
-    if (h) h->error = msg;
-    return status;
-}
 
 extern "C" const char* bsx_status_string(int status) {
     switch (status) {
@@ -136,6 +50,7 @@ extern "C" const char* bsx_status_string(int status) {
         case BSX_ERR_TABLE_FULL: return "result table full";
         case BSX_ERR_STEP_LIMIT: return "internal step limit reached";
         case BSX_ERR_STATE: return "network / problem space not set";
+        case BSX_ERR_COMM: return "RCCL communicator error";
         default: return "unknown status";
     }
 }
@@ -191,6 +106,7 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
 extern "C" int bsx_destroy(bsx_handle h) {
     if (!h) return BSX_OK;
     (void)hipSetDevice(h->device);
+    if (h->comm) (void)bsx_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -440,6 +356,17 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
             std::copy(plan.begin(), plan.end(), sp.deposit);
         }
     }
+    // number of variants = product of the variation radices (batching.py:10-46), saturating at 2^64
+    {
+        unsigned __int128 v = 1;
+        auto times = [&](uint32_t range) { if (v <= UINT64_MAX) v *= (range == BSX_RANGE_MAYBE_TRUE_OR_FALSE ? 3u : 2u); };
+        for (uint32_t j = 0; j < n_fixed_var; ++j) times(fixed_var[j].range);
+        for (uint32_t j = 0; j < n_pert_var; ++j) times(pert_var[j].range);
+        h->variant_count_saturated = v > UINT64_MAX;
+        h->variant_count = h->variant_count_saturated ? UINT64_MAX : (uint64_t)v;
+    }
+    h->tp_max = tp_origin;
+    for (uint32_t j = 0; j < n_pert_var; ++j) h->tp_max = std::max(h->tp_max, pert_var[j].t);
     sp.n_fv = n_fixed_var;
     sp.n_pv = n_pert_var;
     sp.tp_origin = tp_origin;
@@ -475,12 +402,39 @@ Launch plan_persistent(const bsx_engine* h, uint64_t count, size_t shmem) {
     return Launch{dim3((uint32_t)blocks), (uint32_t)chunk};
 }
 
-int check_index(bsx_handle h, const bsx_index* first) {
+// [first, first + count) must lie inside the problem space (2^n_any initial states x variants): the fast
+// enumeration paths add the offset to the digits without looking, so an over-long range would otherwise
+// spill into nodes that are not 'any' and return plausible but wrong counts.
+int check_range(bsx_handle h, const bsx_index* first, uint64_t count) {
     if (!first) return fail(h, BSX_ERR_INVALID, "first index is null");
     const uint32_t n_any = h->sp.n_any;
     for (uint32_t b = n_any; b < 64 * BSX_MAX_WORDS; ++b)
         if ((first->init_digits[b >> 6] >> (b & 63)) & 1ull)
             return fail(h, BSX_ERR_INVALID, "init_digits has bits at or above n_any");
+    if (!h->variant_count_saturated && first->variant >= h->variant_count)
+        return fail(h, BSX_ERR_INVALID, "variant number outside the problem space");
+    if (count == 0) return BSX_OK;
+    // last = init_digits + (count - 1), up to 257 bits; what lies above bit n_any carries into the variant
+    uint64_t sum[5];
+    unsigned __int128 carry = count - 1;
+    for (int w = 0; w < 4; ++w) {
+        carry += first->init_digits[w];
+        sum[w] = (uint64_t)carry;
+        carry >>= 64;
+    }
+    sum[4] = (uint64_t)carry;
+    uint64_t over = 0;                                      // (sum >> n_any); fits 64 bits since count does
+    for (uint32_t b = n_any; b < 320 && b < n_any + 64; ++b)
+        over |= ((sum[b >> 6] >> (b & 63)) & 1ull) << (b - n_any);
+    const uint64_t last_variant = first->variant + over;
+    if (last_variant < over || (!h->variant_count_saturated && last_variant >= h->variant_count))
+        return fail(h, BSX_ERR_INVALID, "first + count runs past the end of the problem space");
+    return BSX_OK;
+}
+
+int check_max_t(bsx_handle h, uint64_t max_t) {
+    if (max_t != BSX_T_INF && max_t < h->tp_max)
+        return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time (origin schedule or a variation)");
     return BSX_OK;
 }
 
@@ -618,14 +572,14 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     if (!h) return BSX_ERR_INVALID;
     if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
     if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
-    if (int rc = check_index(h, first)) return rc;
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
     const double t_begin = now_ms();
     HIPCHK(h, hipSetDevice(h->device));
     *n_out = 0;
     if (n_no_attractor) *n_no_attractor = 0;
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
-    if (max_t != BSX_T_INF && max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
     if (count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call");
 
     DevBuf<LogRec>& d_log = h->d_log;
@@ -839,7 +793,8 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
     if (!h) return BSX_ERR_INVALID;
     if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
     if (!mask_words || !code_words || !n_hits || (cap && !hits)) return fail(h, BSX_ERR_INVALID, "null argument");
-    if (int rc = check_index(h, first)) return rc;
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
     const double t_begin = now_ms();
     HIPCHK(h, hipSetDevice(h->device));
     *n_hits = 0;
@@ -1045,8 +1000,8 @@ extern "C" int bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t c
                                 bsx_stats* stats) {
     if (!h) return BSX_ERR_INVALID;
     if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
-    if (int rc = check_index(h, first)) return rc;
-    if (max_t < h->sp.tp_origin) return fail(h, BSX_ERR_INVALID, "max_t is below the last perturbation time");
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
     // Long fixed-length runs that only want final states go through the bit-sliced kernel
     // (BSX_SLICED=0 forces the per-lane kernel, for A/B runs and tests).
     const char* sl_env = std::getenv("BSX_SLICED");
@@ -1064,9 +1019,10 @@ extern "C" int bsx_run_trajectories(bsx_handle h, const bsx_index* first, const 
                                     const uint64_t* out_offsets, bsx_stats* stats) {
     if (!h) return BSX_ERR_INVALID;
     if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
-    if (int rc = check_index(h, first)) return rc;
     if (n && (!offsets || !t_len || !out || !out_offsets)) return fail(h, BSX_ERR_INVALID, "null argument");
-    uint64_t words = 0, tmax = 0;
+    uint64_t words = 0, tmax = 0, off_max = 0;
+    for (uint64_t q = 0; q < n; ++q) off_max = std::max(off_max, offsets[q]);
+    if (int rc = check_range(h, first, n ? off_max + 1 : 0)) return rc;
     for (uint64_t q = 0; q < n; ++q) {
         words = std::max(words, out_offsets[q] + (t_len[q] + 1) * h->w64);
         tmax = std::max(tmax, t_len[q]);

@@ -1,0 +1,110 @@
+// Host-side internals shared by the translation units behind include/bsx.h (bsx_api.cpp, bsx_comm.cpp,
+// bsx_fgraph.hip): the engine handle, device buffers, error plumbing.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "bsx.h"
+#include "bsx_device.h"
+
+namespace bsx {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t reserve(size_t count) { return n >= count ? hipSuccess : alloc(count); }     // grow-only scratch
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+}  // namespace bsx
+
+struct bsx_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop{};
+    std::string error;
+
+    // network
+    bool have_net = false;
+    uint32_t n_nodes = 0, w64 = 0;
+    bsx::DevNet net{};
+    int lut_mode = 0;           // kLutGlobal / kLutLdsByte / kLutLdsNibble (bsx_kernels_common.h)
+    size_t shmem = 0;           // masks (+ LUT) : target / simulate kernels
+    size_t shmem_attract = 0;   // + LDS mirror of the cycle-state cache
+
+    // cycle-state cache (valid for the current network + origin fixed nodes)
+    bool cache_enabled = true;
+    int lean_blocks_per_cu = 0;  // occupancy of the lean attract kernel for the current network
+    bool fast_ok = true;        // cleared when the lean kernel's straggler list overflowed for this space
+    bool pool_ok = false;       // the class-pool kernel fits the LDS for this network
+    size_t cache_stride = 0;    // bytes per slot of the LDS cache mirror
+    std::vector<bsx::CycleRecord> h_journal;
+    bool journal_stale = true;  // a general-kernel pass (the only writer of the journal) ran since h_journal was read
+    uint32_t mirror_slots = 64;
+    uint32_t fast_steps = 0;    // lean kernel: steps without a cached cycle state before a problem is handed over (0 = default)
+    bool fast_calibrated = false;
+    uint32_t cache_lds_slots = 0;
+    bsx::DevBuf<bsx::CycleRecord> d_cc_journal;
+    bsx::DevBuf<unsigned int> d_cc_claims;
+    bsx::DevBuf<unsigned int> d_cc_count;
+
+    // scratch kept across calls (grow-only): hipMalloc / hipFree per call cost ~1 ms of a 16 ms step
+    bsx::DevBuf<bsx::LogRec> d_log;
+    bsx::DevBuf<uint32_t> d_strag;
+    bsx::DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
+
+    // host copies for the bit-sliced simulate kernel's node descriptors
+    std::vector<uint32_t> h_pred_offsets, h_pred_idx;
+    std::vector<uint64_t> h_tt0;        // first table word of every node (all of it when k <= 6)
+    std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
+
+    // problem space
+    bool have_space = false;
+    uint64_t variant_count = 1;         // product of the variation radices ...
+    bool variant_count_saturated = false;   // ... unless it does not fit 64 bits
+    uint32_t tp_max = 0;                // last perturbation time over origin schedule and variations
+    bsx::DevSpace sp{};
+    bsx::DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
+
+    bsx::DevBuf<bsx::Counters> d_ctr;
+
+    // RCCL communicator of this handle's rank (bsx_comm.cpp); librccl is loaded on first use
+    void* comm = nullptr;       // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    bsx::DevBuf<unsigned char> d_comm_send, d_comm_recv;
+};
+
+#define HIPCHK(h, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (h)->error = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return BSX_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+static inline int fail(bsx_handle h, int status, const std::string& msg) {
+    if (h) h->error = msg;
+    return status;
+}
+

@@ -3,108 +3,276 @@ Multi-GPU layer: one process per GPU, problems range-partitioned, one all-gather
 
 Replaces the reference's mpi4py master/worker task farm (boolsi/mpi.py:193-340, 379-495): the
 simulation problems are independent, so rank r simply takes the contiguous index range
-[r*N/G, (r+1)*N/G) and the only communication is the merge of the per-rank attractor tables --
-`torch.distributed.all_gather` of fixed-size integer records (backend "nccl" = RCCL over xGMI on
-GPUs, "gloo" on CPU for the tests).  torch is used for this control/collective plumbing only and is
-imported lazily, so single-GPU runs never load it.
+[r*N/G, (r+1)*N/G) and the only data exchange is the merge of the per-rank result tables -- ONE
+`ncclAllGather` (RCCL over xGMI) of fixed-size integer records, issued through the engine's C-ABI
+(`bsx_comm_allgather`, include/bsx.h) on the engine's own device and stream.
+
+Two planes:
+  control  `Bootstrap`: a TCP star on the launcher's MASTER_ADDR (rank 0 is the hub).  It carries the
+           128-byte ncclUniqueId from rank 0 to the others, barriers, the record counts that size the
+           all-gather, scalar reductions of run statistics, and it is how a rank learns that a peer has
+           died (closed socket) instead of blocking in a collective for ever.  Pure Python, no MPI, no
+           torch.  Rendezvous: rank 0 listens on an ephemeral port and publishes it in a file named
+           after MASTER_PORT and the launcher's pid (the port itself belongs to the launcher's store).
+  data     RCCL, once `attach_engine` has built the communicator.  Without an engine the data collectives
+           refuse to run unless BSX_DIST_BACKEND=socket explicitly routes them through the control
+           plane -- that is for CPU-only tests and for rehearsing several ranks on ONE GPU (RCCL wants
+           one device per rank); it is never picked silently.
 """
+import hashlib
 import os
+import pickle
+import socket
+import struct
+import tempfile
+import time
 
 import numpy as np
 
 from . import _lib
 
+_MAGIC = b'BSX1'
+
+
+class PeerLost(RuntimeError):
+    """A rank of the job went away (its control connection closed) or reported a failure."""
+
+
+def _recv_exact(sock, n):
+    chunks, got = [], 0
+    while got < n:
+        part = sock.recv(min(n - got, 1 << 20))
+        if not part:
+            raise PeerLost('a rank of the job closed its control connection')
+        chunks.append(part)
+        got += len(part)
+    return b''.join(chunks)
+
+
+def _send_frame(sock, payload):
+    sock.sendall(struct.pack('<Q', len(payload)) + payload)
+
+
+def _recv_frame(sock):
+    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class Bootstrap:
+    """Control plane of a job: all-gather of small byte strings over a TCP star (rank 0 = hub)."""
+
+    def __init__(self, rank, world, addr, key, timeout=300.0):
+        self.rank, self.world = rank, world
+        self._peers = {}            # hub: rank -> socket
+        self._hub = None            # others: socket to rank 0
+        self._listener = None
+        digest = hashlib.sha256(key.encode()).digest()
+        directory = os.environ.get('BSX_RDZV_DIR', tempfile.gettempdir())
+        self._path = os.path.join(directory, 'bsx_rdzv_{}_{}'.format(os.getuid(), digest[:8].hex()))
+        deadline = time.monotonic() + timeout
+        if rank == 0:
+            self._listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            self._listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            self._listener.bind((addr, 0))
+            self._listener.listen(world)
+            nonce = os.urandom(8)
+            tmp = '{}.{}'.format(self._path, os.getpid())
+            with open(tmp, 'wb') as f:
+                f.write(struct.pack('<I', self._listener.getsockname()[1]) + nonce)
+            os.replace(tmp, self._path)         # atomic: readers see the old file or the whole new one
+            while len(self._peers) < world - 1:
+                self._listener.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = self._listener.accept()
+                except socket.timeout:
+                    raise PeerLost('only {} of {} ranks joined the job within {} s'.format(
+                        len(self._peers) + 1, world, timeout))
+                conn.settimeout(10.0)
+                try:
+                    hello = _recv_exact(conn, 4 + 8 + 8 + 8)
+                    peer, pworld = struct.unpack('<QQ', hello[12:])
+                    if hello[:4] != _MAGIC or hello[4:12] != digest[8:16] or pworld != world or not 0 < peer < world \
+                            or peer in self._peers:
+                        raise ValueError
+                    conn.sendall(nonce)
+                except (ValueError, PeerLost, OSError):
+                    conn.close()                # not one of ours (stale client, port scanner)
+                    continue
+                conn.settimeout(None)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self._peers[peer] = conn
+        else:
+            while self._hub is None:
+                if time.monotonic() > deadline:
+                    raise PeerLost('rank 0 did not publish its control port within {} s ({})'.format(timeout, self._path))
+                try:
+                    with open(self._path, 'rb') as f:
+                        blob = f.read()
+                    (port,), nonce = struct.unpack('<I', blob[:4]), blob[4:12]
+                    conn = socket.create_connection((addr, port), timeout=5.0)
+                    conn.sendall(_MAGIC + digest[8:16] + struct.pack('<QQ', rank, world))
+                    if _recv_exact(conn, 8) != nonce:
+                        raise ValueError
+                    conn.settimeout(None)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self._hub = conn
+                except (OSError, ValueError, struct.error, PeerLost):
+                    time.sleep(0.05)            # file not there yet, or left over from an earlier job
+        if rank == 0:
+            try:
+                os.unlink(self._path)           # everyone is connected; the file has done its job
+            except OSError:
+                pass
+
+    def allgather(self, payload):
+        """payload (bytes) of every rank, in rank order.  Collective: every rank calls it in the same order."""
+        if self.world == 1:
+            return [payload]
+        try:
+            if self.rank == 0:
+                parts = [payload] + [_recv_frame(self._peers[r]) for r in range(1, self.world)]
+                joined = b''.join(struct.pack('<Q', len(p)) + p for p in parts)
+                for r in range(1, self.world):
+                    _send_frame(self._peers[r], joined)
+                return parts
+            _send_frame(self._hub, payload)
+            joined = _recv_frame(self._hub)
+        except OSError as e:
+            raise PeerLost('control connection failed: {}'.format(e))
+        parts, at = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from('<Q', joined, at)
+            parts.append(joined[at + 8:at + 8 + n])
+            at += 8 + n
+        return parts
+
+    def close(self):
+        for s in list(self._peers.values()) + [self._hub, self._listener]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers, self._hub, self._listener = {}, None, None
+
 
 class Comm:
-    """World of size 1 unless initialised from the torchrun environment."""
+    """World of size 1 unless initialised from the launcher's environment (RANK / WORLD_SIZE / MASTER_*)."""
 
     def __init__(self):
         self.rank = 0
         self.world = 1
         self.local_rank = 0
-        self.backend = None
-        self._dist = None
-        self._torch = None
+        self.backend = None         # 'rccl' | 'socket' (data plane), None for a world of 1
+        self._boot = None
+        self._engine = None         # engine whose handle owns the RCCL communicator
 
     @classmethod
     def from_env(cls, backend=None):
         c = cls()
-        world = int(os.environ.get('WORLD_SIZE', '1'))
-        if world <= 1 and not os.environ.get('BSX_FORCE_DIST'):
+        world = max(1, int(os.environ.get('WORLD_SIZE', '1')))
+        if world == 1 and not os.environ.get('BSX_FORCE_DIST'):     # (knob: tests run the full machinery with one rank)
             return c
-        import torch
-        import torch.distributed as dist
         c.rank = int(os.environ.get('RANK', '0'))
         c.world = world
         c.local_rank = int(os.environ.get('LOCAL_RANK', c.rank))
-        c.backend = backend or os.environ.get('BSX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
-        if c.backend == 'nccl':
-            torch.cuda.set_device(c.local_rank)
-        if not dist.is_initialized():
-            dist.init_process_group(backend=c.backend, rank=c.rank, world_size=world)
-        c._dist, c._torch = dist, torch
+        c.backend = backend or os.environ.get('BSX_DIST_BACKEND') or 'rccl'
+        if c.backend not in ('rccl', 'socket'):
+            raise ValueError('BSX_DIST_BACKEND must be "rccl" or "socket", not "{}"'.format(c.backend))
+        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        key = os.environ.get('BSX_RDZV_KEY') or '{}|{}|{}|{}|{}'.format(
+            addr, os.environ.get('MASTER_PORT', ''), os.environ.get('TORCHELASTIC_RUN_ID', ''),
+            os.environ.get('TORCHELASTIC_RESTART_COUNT', ''), os.getppid())
+        c._boot = Bootstrap(c.rank, world, addr, key, float(os.environ.get('BSX_RDZV_TIMEOUT', '300')))
         return c
 
-    # -- helpers ----------------------------------------------------------------------------
-    def _device(self):
-        return self._torch.device('cuda', self.local_rank) if self.backend == 'nccl' else self._torch.device('cpu')
+    @property
+    def active(self):
+        """True when collectives really run (a job of several ranks, or the forced one-rank test mode)."""
+        return self._boot is not None
 
+    def attach_engine(self, engine):
+        """Build this job's RCCL communicator on the engine's device (collective).  No-op for a world of 1
+        and for the socket backend."""
+        if self._boot is None or self.backend != 'rccl' or self._engine is engine:
+            return
+        # every rank asks its library for an id first (only rank 0's is used): a rank whose librccl does not
+        # load says so here, over the control plane, instead of leaving the others inside ncclCommInitRank
+        uid, err = b'', None
+        try:
+            uid = engine.comm_unique_id()
+        except Exception as e:      # noqa: BLE001
+            err = e
+        flags = self._boot.allgather(b'' if err else uid)
+        if err:
+            raise err
+        bad = [r for r, f in enumerate(flags) if not f]
+        if bad:
+            raise PeerLost('RCCL is not usable on rank(s) {}'.format(bad))
+        engine.comm_init(flags[0], self.rank, self.world)
+        self._engine = engine
+
+    # -- control plane ------------------------------------------------------------------------
     def barrier(self):
-        if self.world > 1:
-            self._dist.barrier()
-            if self.backend == 'nccl':
-                self._torch.cuda.synchronize()
+        if self._boot is not None:
+            self._boot.allgather(b'')
+
+    def broadcast_obj(self, obj, root=0):
+        """Python object of `root` on every rank (control plane: small things such as the output directory)."""
+        if self._boot is None:
+            return obj
+        return pickle.loads(self._boot.allgather(pickle.dumps(obj) if self.rank == root else b'')[root])
+
+    def allgather_obj(self, obj):
+        if self._boot is None:
+            return [obj]
+        return [pickle.loads(p) for p in self._boot.allgather(pickle.dumps(obj))]
 
     def allreduce_max(self, value):
-        if self.world == 1:
-            return float(value)
-        t = self._torch.tensor([float(value)], dtype=self._torch.float64, device=self._device())
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t.item())
+        return max(float(v) for v in self.allgather_obj(float(value)))
 
     def allreduce_sum_int(self, values):
-        """Element-wise sum of a list of non-negative python ints (< 2^62 each) over ranks."""
-        if self.world == 1:
-            return [int(v) for v in values]
-        t = self._torch.tensor([int(v) for v in values], dtype=self._torch.int64, device=self._device())
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return [int(v) for v in t.tolist()]
+        """Element-wise sum of a list of python ints over ranks (exact, any size)."""
+        rows = self.allgather_obj([int(v) for v in values])
+        return [sum(col) for col in zip(*rows)]
 
-    def allgather_records(self, records, expect=64):
+    def all_ok(self, ok):
+        """True iff every rank passes True.  Lets a rank-local failure end the whole job together."""
+        return all(self.allgather_obj(bool(ok)))
+
+    # -- data plane ---------------------------------------------------------------------------
+    def _allgather_bytes(self, raw, per_rank):
+        """raw: uint8 array of exactly per_rank bytes -> (world, per_rank) uint8 array."""
+        if self.backend == 'rccl':
+            if self._engine is None:
+                raise RuntimeError('no RCCL communicator: call Comm.attach_engine(engine) first '
+                                   '(BSX_DIST_BACKEND=socket routes the merge over TCP for CPU-only tests)')
+            return self._engine.comm_allgather(raw, self.world).reshape(self.world, per_rank)
+        parts = self._boot.allgather(raw.tobytes())
+        return np.frombuffer(b''.join(parts), np.uint8).reshape(self.world, per_rank)
+
+    def allgather_records(self, records):
         """
         All-gather a 1-D numpy structured array (e.g. _lib.ATTR_REC) -> list of per-rank arrays.
-        One collective when every rank has at most `expect` records (the usual case: a handful of
-        attractors): each rank sends an 8-byte count followed by `expect` record slots.  If some rank has
-        more, every rank sees that in the counts and a second collective moves the records padded to the
-        common maximum.
+        The counts go over the control plane first, so the data plane is exactly ONE all-gather of
+        max(count) record slots per rank (none at all if nobody has a record).
         """
-        if self.world == 1:
+        if self._boot is None:
             return [records]
-        torch, dist = self._torch, self._dist
-        dev = self._device()
+        counts = self.allgather_obj(len(records))
+        cap = max(counts)
         item = records.dtype.itemsize
+        if cap == 0:
+            return [np.zeros(0, records.dtype) for _ in counts]
+        buf = np.zeros(cap * item, np.uint8)
         raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
-
-        def exchange(cap):
-            buf = np.zeros(8 + cap * item, np.uint8)
-            buf[:8] = np.frombuffer(np.uint64(len(records)).tobytes(), np.uint8)
-            n = min(len(records), cap) * item
-            buf[8:8 + n] = raw[:n]
-            mine = torch.from_numpy(buf).to(dev)
-            gathered = torch.empty(self.world * buf.size, dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(gathered, mine)
-            host = gathered.cpu().numpy().reshape(self.world, buf.size)
-            counts = [int(np.frombuffer(host[r, :8].tobytes(), np.uint64)[0]) for r in range(self.world)]
-            return host, counts
-
-        host, counts = exchange(expect)
-        if max(counts) > expect:
-            host, counts = exchange(max(counts))
-        return [np.frombuffer(host[r, 8:8 + c * item].tobytes(), dtype=records.dtype) for r, c in enumerate(counts)]
+        buf[:raw.size] = raw
+        host = self._allgather_bytes(buf, cap * item)
+        return [np.frombuffer(host[r, :c * item].tobytes(), dtype=records.dtype) for r, c in enumerate(counts)]
 
     def gather_concat(self, array):
         """All-gather a numpy array along axis 0 (rank order = index order for range partitions)."""
-        if self.world == 1:
+        if self._boot is None:
             return array
         flat = np.ascontiguousarray(array)
         row = flat.dtype.itemsize * int(np.prod(flat.shape[1:], dtype=np.int64))
@@ -115,8 +283,17 @@ class Comm:
         return joined.view(flat.dtype).reshape((-1,) + flat.shape[1:])
 
     def shutdown(self):
-        if self._dist is not None and self._dist.is_initialized():
-            self._dist.destroy_process_group()
+        if self._engine is not None:
+            try:
+                self._engine.comm_destroy()
+            except Exception:   # noqa: BLE001  (engine already closed)
+                pass
+            self._engine = None
+        if self._boot is not None:
+            self._boot.close()
+            self._boot = None
+
+    abort = shutdown            # closing the control connection is what tells the peers
 
 
 def partition(n_problems, world, rank):

@@ -85,6 +85,26 @@ class Engine:
     def synchronize(self):
         self._check(self._lib.bsx_synchronize(self._h))
 
+    # -- multi-GPU merge step (RCCL through the C-ABI; driven by boolsi_amd.dist.Comm) -----------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        self._check(self._lib.bsx_comm_unique_id(self._h, buf, _lib.COMM_ID_BYTES))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self._lib.bsx_comm_init(self._h, unique_id, len(unique_id), int(rank), int(world)))
+
+    def comm_allgather(self, send, world):
+        """send: contiguous uint8 array, same size on every rank -> uint8 array of world * size bytes."""
+        send = np.ascontiguousarray(send, np.uint8)
+        recv = np.zeros(world * send.size, np.uint8)
+        self._check(self._lib.bsx_comm_allgather(self._h, ptr(send), send.size, ptr(recv)))
+        return recv
+
+    def comm_destroy(self):
+        if getattr(self, '_h', None):
+            self._check(self._lib.bsx_comm_destroy(self._h))
+
     # -- problem definition -----------------------------------------------------------------
     def set_problem(self, net, space):
         """net, space: boolsi_amd.compile.CompiledNetwork / CompiledSpace."""

@@ -521,12 +521,14 @@ def parse_input_text(text, max_t, mode):
     return parse_input_data(yaml.load(text, Loader=UniqueKeyLoader), max_t, mode)
 
 
-def process_input(input_file, output_directory, max_t, mode):
-    """Copy the input next to the outputs, parse, map validation failures (reference: input.py:75-95)."""
-    try:
-        copy2(input_file, output_directory)
-    except IOError as e:
-        logging.getLogger().warning('Failed to copy input file into the output directory: {}'.format(e))
+def process_input(input_file, output_directory, max_t, mode, copy_input=True):
+    """Copy the input next to the outputs, parse, map validation failures (reference: input.py:75-95).
+    copy_input: in a multi-rank job only the rank that owns the output directory copies."""
+    if copy_input:
+        try:
+            copy2(input_file, output_directory)
+        except IOError as e:
+            logging.getLogger().warning('Failed to copy input file into the output directory: {}'.format(e))
     try:
         return parse_input(input_file, max_t, mode)
     except (ValueError, KeyError, DuplicateKeyError) as e:

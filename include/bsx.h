@@ -44,7 +44,8 @@ typedef enum {
     BSX_ERR_TABLE_FULL = -5,     /* more distinct attractors / hits than the caller's capacity */
     BSX_ERR_STEP_LIMIT = -6,     /* a trajectory ran into the engine's internal step limit
                                     (only possible when max_t is BSX_T_INF or above that limit) */
-    BSX_ERR_STATE = -7           /* call order: network / problem space not set */
+    BSX_ERR_STATE = -7,          /* call order: network / problem space not set */
+    BSX_ERR_COMM = -8            /* RCCL: library not loadable, or an ncclXxx call failed */
 } bsx_status;
 
 /* Variation ranges = boolsi.constants.NodeStateRange (constants.py:23-30), digit -> state as in
@@ -163,6 +164,23 @@ int  bsx_run_trajectories(bsx_handle h, const bsx_index* first, const uint64_t* 
 
 /* Blocks until all work of the handle's stream is done (bench.py's timing fence). */
 int  bsx_synchronize(bsx_handle h);
+
+/* Multi-GPU merge step: one process per GPU, the problem index range-partitioned by the caller
+ * ([r*N/G, (r+1)*N/G) for rank r), and ONE all-gather of the per-rank result tables at the end --
+ * the counterpart of the reference master collecting its workers' batch results (mpi.py:290-330).
+ * The collective is ncclAllGather (RCCL over xGMI) on the handle's stream.  The caller moves the
+ * BSX_COMM_ID_BYTES unique id from rank 0 to the other ranks (any side channel: file, socket);
+ * librccl.so is loaded on the first of these calls.
+ *   bsx_comm_unique_id   rank 0 only: a fresh id (ncclGetUniqueId)
+ *   bsx_comm_init        every rank, collectively: communicator of `world` ranks on the handle's device
+ *   bsx_comm_allgather   every rank, collectively: recv[r * bytes_per_rank ..) = rank r's send buffer
+ *                        (host buffers; staged through HBM by the library)
+ *   bsx_comm_destroy     releases the communicator (bsx_destroy does it too) */
+#define BSX_COMM_ID_BYTES 128
+int  bsx_comm_unique_id(bsx_handle h, void* out, uint32_t cap);
+int  bsx_comm_init(bsx_handle h, const void* unique_id, uint32_t id_bytes, int rank, int world);
+int  bsx_comm_allgather(bsx_handle h, const void* send, uint64_t bytes_per_rank, void* recv);
+int  bsx_comm_destroy(bsx_handle h);
 
 #ifdef __cplusplus
 }

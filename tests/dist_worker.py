@@ -1,4 +1,4 @@
-"""Worker of tests/test_dist_gloo.py: one rank of a world_size-N gloo job (CPU)."""
+"""Worker of tests/test_dist_ranks.py: one rank of a world_size-N job on CPU (socket data plane)."""
 import json
 import os
 import sys
@@ -20,7 +20,7 @@ from oracle.cpu_oracle import Oracle  # noqa: E402   (stands in for the GPU engi
 
 def main():
     out_path = sys.argv[1]
-    comm = Comm.from_env(backend='gloo')
+    comm = Comm.from_env(backend='socket')
     cfg = parse_input_text(synth.config3_yaml(), 4096, Mode.ATTRACT)
     net, space = compile_problem(cfg)
     n_total = 20000 + 13                      # ragged on purpose

@@ -155,11 +155,11 @@ def test_cli_reference_np_changes_order_only(tmp_path):
     assert blocks(a) == blocks(b)
 
 
-# ----------------------------------------------------------------------------- two ranks (one GPU shared, gloo)
+# ----------------------------------------------------------------------------- two ranks (one GPU shared, socket data plane)
 
-def run_cli_world(args, out_dir, world=2):
-    """The CLI as `torch.distributed.run` starts it, `world` ranks sharing GPU 0 (gloo for the collectives:
-    RCCL wants one device per rank)."""
+def run_cli_world(args, out_dir, world=2, cwd=ROOT):
+    """The CLI as `torch.distributed.run` starts it, `world` ranks sharing GPU 0 (BSX_DIST_BACKEND=socket for
+    the data collectives: RCCL wants one device per rank)."""
     import socket
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -167,9 +167,10 @@ def run_cli_world(args, out_dir, world=2):
     procs = []
     for rank in range(world):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world),
-                   RANK=str(rank), LOCAL_RANK=str(rank), BSX_DIST_BACKEND='gloo')
-        cmd = [sys.executable, '-m', 'boolsi_amd'] + args + ['-o', out_dir, '--device', '0']
-        procs.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                   RANK=str(rank), LOCAL_RANK=str(rank), BSX_DIST_BACKEND='socket')
+        env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+        cmd = [sys.executable, '-m', 'boolsi_amd'] + args + (['-o', out_dir] if out_dir else []) + ['--device', '0']
+        procs.append(subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs) and not any('Exception caught' in o for o in outs), '\n'.join(outs)
     return outs
@@ -194,3 +195,34 @@ def test_two_ranks_write_the_same_files_as_one(tmp_path):
         assert files and files == sorted(f for f in os.listdir(tmp_path / (name + '2')) if f.endswith('.csv'))
         for f in files:
             assert read(tmp_path / (name + '1') / f) == read(tmp_path / (name + '2') / f), (name, f)
+
+
+def test_ranks_agree_on_the_default_output_directory(tmp_path):
+    """Without -o every process would name its own `output_<timestamp>`; rank 0's name must be the one, created
+    before anybody writes, and no stray file may appear next to it (cli.py race)."""
+    (tmp_path / 'att.yaml').write_text(load('attract_toy.json')[0]['yaml'])
+    work = tmp_path / 'cwd'
+    work.mkdir()
+    outs = run_cli_world(['attract', str(tmp_path / 'att.yaml')], None, world=3, cwd=str(work))
+    made = sorted(os.listdir(work))
+    assert len(made) == 1 and made[0].startswith('output_') and os.path.isdir(work / made[0]), (made, outs)
+    files = os.listdir(work / made[0])
+    assert 'att.yaml' in files and 'attractor_summaries.csv' in files
+
+
+def test_failing_rank_ends_the_job_with_a_nonzero_status(tmp_path):
+    """One rank cannot open its GPU: it must not exit 0 while its peers wait in the merge."""
+    (tmp_path / 'att.yaml').write_text(load('attract_toy.json')[0]['yaml'])
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', RANK=str(rank),
+                   LOCAL_RANK=str(rank), BSX_DIST_BACKEND='socket')
+        cmd = [sys.executable, '-m', 'boolsi_amd', 'attract', str(tmp_path / 'att.yaml'), '-o', str(tmp_path / 'out'),
+               '--device', '0' if rank == 0 else '99']
+        procs.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [1, 1], outs
