@@ -18,8 +18,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 EXPORTS = (
     'bsx_create', 'bsx_destroy', 'bsx_last_error', 'bsx_status_string', 'bsx_device_info',
-    'bsx_set_network', 'bsx_set_problem_space', 'bsx_run_attract', 'bsx_run_target',
-    'bsx_run_simulate', 'bsx_run_trajectories', 'bsx_synchronize',
+    'bsx_set_network', 'bsx_set_problem_space', 'bsx_run_attract', 'bsx_run_attract_fgraph', 'bsx_run_target',
+    'bsx_run_target_summary', 'bsx_run_simulate', 'bsx_run_trajectories', 'bsx_synchronize',
     'bsx_comm_unique_id', 'bsx_comm_init', 'bsx_comm_allgather', 'bsx_comm_destroy',
 )
 COMM_ID_BYTES = 128
@@ -86,8 +86,12 @@ def load():
     lib.bsx_set_problem_space.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32]
     lib.bsx_run_attract.argtypes = [vp, C.POINTER(Index), u64, u64, u64, vp, u32, C.POINTER(u32),
                                     C.POINTER(u64), vp, C.POINTER(Stats)]
+    lib.bsx_run_attract_fgraph.argtypes = [vp, C.POINTER(Index), u64, u64, u64, vp, u32, C.POINTER(u32),
+                                           C.POINTER(u64), C.POINTER(Stats)]
     lib.bsx_run_target.argtypes = [vp, C.POINTER(Index), u64, u64, vp, vp, vp, u64, C.POINTER(u64),
                                    C.POINTER(Stats)]
+    lib.bsx_run_target_summary.argtypes = [vp, C.POINTER(Index), u64, u64, vp, vp, vp, u32, vp, u64, C.POINTER(u64),
+                                           C.POINTER(u64), C.POINTER(Stats)]
     lib.bsx_run_simulate.argtypes = [vp, C.POINTER(Index), u64, u64, vp, vp, vp, C.POINTER(Stats)]
     lib.bsx_run_trajectories.argtypes = [vp, C.POINTER(Index), vp, vp, u64, vp, vp, C.POINTER(Stats)]
     lib.bsx_synchronize.argtypes = [vp]

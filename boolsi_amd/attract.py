@@ -20,7 +20,8 @@ from .dist import Comm, partition
 from .engine import key_to_int
 from .model import decode_state
 
-MAX_TILE = 1 << 32      # problems per engine call
+MAX_TILE = 1 << 48      # problems per engine call: ranges that collapse into cubes
+PLAIN_TILE = 1 << 32    # ... and the limit for those that do not
 
 
 class AggregatedAttractor:
@@ -78,10 +79,17 @@ def run_attract_range(engine, first, count, max_t=inf, max_attractor_l=inf, cap=
     merged_tables, none = [], 0
     stats = {'problems': 0, 'state_steps': 0, 'executed_steps': 0, 'kernel_ms': 0.0, 'total_ms': 0.0,
              'kernel_launches': 0}
-    done = 0
+    from .engine import EngineError
+    done, limit = 0, MAX_TILE
     while done < count:
-        tile = min(MAX_TILE, count - done)
-        r = engine.attract(first + done, tile, max_t, max_attractor_l, cap=cap)
+        tile = min(limit, count - done)
+        try:
+            r = engine.attract(first + done, tile, max_t, max_attractor_l, cap=cap)
+        except EngineError as e:
+            if e.status != -4 or limit == PLAIN_TILE:
+                raise
+            limit = PLAIN_TILE      # this space does not collapse: plain enumeration, 2^32 problems at a time
+            continue
         merged_tables.append(r.table)
         none += r.n_no_attractor
         for k in stats:

@@ -10,7 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -30,6 +30,19 @@ hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
 size_t pool_extra_bytes(uint32_t nw);
+hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, uint32_t fixmask,
+                          uint32_t fixval, uint64_t n_states, uint32_t* succ);
+hipError_t launch_fg_double(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t cus, hipStream_t st);
+hipError_t launch_fg_mark(const uint32_t* land, uint64_t n, uint32_t* bits, uint32_t cus, hipStream_t st);
+hipError_t launch_fg_collect(uint32_t* bits, uint64_t n_words, uint32_t* cand, uint32_t cand_cap, unsigned int* cursor, uint32_t cus, hipStream_t st);
+hipError_t launch_fg_cycles(const uint32_t* succ, const uint32_t* cand, uint32_t n_cand, uint64_t walk_cap, void* cyc, uint32_t cyc_mask,
+                            unsigned int* n_cyclic, unsigned int* n_open, hipStream_t st);
+hipError_t launch_fg_pair_init(const uint32_t* succ, const void* cyc, uint32_t cyc_mask, unsigned long long* pair, uint64_t n, uint32_t cus, hipStream_t st);
+hipError_t launch_fg_pair_jump(unsigned long long* pair, uint64_t n, uint32_t d_cap, unsigned int* changed, uint32_t cus, hipStream_t st);
+hipError_t launch_fg_aggregate(const unsigned long long* pair, const void* cyc, uint32_t cyc_mask, uint64_t first, uint64_t count,
+                               uint64_t cap_rel, uint64_t max_len, uint64_t max_t, const AttractParams& P, uint32_t cus, hipStream_t st);
+size_t fg_cyc_entry_bytes();
+hipError_t launch_table_drain(LogRec* tab, uint64_t slots, LogRec* out, uint64_t out_cap, unsigned long long* cursor, hipStream_t st);
 hipError_t configure_target(int nw, int k, int lut_mode, size_t shmem);
 hipError_t configure_simulate(int nw, int k, int lut_mode, size_t shmem);
 }  // namespace bsx
@@ -253,7 +266,7 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
         if (h->pool_ok) HIPCHK(h, configure_attract_pool((int)nw, (int)k_mux, h->lut_mode, std::min<size_t>(pool_max, 160 * 1024 - 1024), &blocks));
     }
     if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] network: nw %u k_mux %u lut mode %d (0 L2 bytes, 1 LDS bytes, 2 LDS nibbles) shmem %zu attract shmem %zu lean blocks/CU %d\n", nw, k_mux, (int)h->lut_mode, h->shmem, h->shmem_attract, h->lean_blocks_per_cu);
-    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_mode, h->shmem));
+    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_mode, h->shmem + 16 + kTargetHistBins * 4));
     HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_mode, h->shmem));
     h->have_net = true;
     return BSX_OK;
@@ -323,6 +336,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
         h->h_sched.clear();
         for (const auto& e : ordered) { h->h_sched.push_back(e[0]); h->h_sched.push_back(e[1]); h->h_sched.push_back(e[2]); }
     }
+    h->h_any = any;
     HIPCHK(h, h->d_any.upload(any));
     HIPCHK(h, h->d_fv.upload(fv));
     HIPCHK(h, h->d_pv.upload(pv));
@@ -448,9 +462,16 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-struct KeyLess {
-    bool operator()(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) const { return a < b; }
+// attractor key as the table key of the host-side merge (zero padded to the longest state)
+using Key8 = std::array<uint32_t, kMaxW32>;
+struct Key8Hash {
+    size_t operator()(const Key8& k) const {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (uint32_t w : k) h = (h ^ w) * 0xBF58476D1CE4E5B9ull;
+        return (size_t)(h ^ (h >> 29));
+    }
 };
+inline Key8 key8(const uint32_t* words) { Key8 k; std::copy(words, words + kMaxW32, k.begin()); return k; }
 
 }  // namespace
 
@@ -462,8 +483,10 @@ constexpr uint64_t kLeanTile = 1ull << 28;      // problems per lean-kernel laun
 constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps without a cached cycle state), first guess
 constexpr uint32_t kFastStepsMax = 3072;
 constexpr uint64_t kProbeTile = 1ull << 22;     // lean tiles while the FAST length is being calibrated
+constexpr uint32_t kCubeMinBits = 16;           // cube collapse: smallest aligned block handled as a cube
+constexpr uint32_t kCubeMaxBits = 48;           // ... and the largest (= the per-call limit)
 
-using MergedTable = std::map<std::vector<uint32_t>, bsx_attr_rec, KeyLess>;
+using MergedTable = std::unordered_map<Key8, bsx_attr_rec, Key8Hash>;
 
 struct AttractRun {
     Counters ctr{};
@@ -476,8 +499,17 @@ enum PassKind { kPassGeneral = 0, kPassLean = 1, kPassPool = 2 };
 // LDS mirror size for the lean / pool kernels: they fill the mirror once from the journal, so it only has
 // to hold what the journal holds (4 slots per state keeps probe chains short); a smaller mirror leaves
 // the LDS to more workgroups.  The general kernel inserts while it runs and keeps the full size.
+int mirror_slots_for(bsx_handle h, uint32_t* slots_out) {
+    // 4 slots per state keep probe chains short; a cube pass adds one representative entry per state
+    const uint64_t want = (h->cube_mirror ? 8 : 4) * h->journal_states;
+    uint32_t slots = 64;
+    while (slots < want && slots < h->cache_lds_slots) slots *= 2;
+    h->mirror_slots = *slots_out = std::min(slots, h->cache_lds_slots);
+    return BSX_OK;
+}
+
 int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
-    if (!h->journal_stale) { *slots_out = h->mirror_slots; return BSX_OK; }
+    if (!h->journal_stale) return mirror_slots_for(h, slots_out);
     unsigned int known = 0;
     HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
     known = std::min<unsigned int>(known, kCycleJournalCap);
@@ -491,12 +523,12 @@ int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
         states += r.length;
         ++taken;
     }
-    uint32_t slots = 64;
-    while (slots < 4 * states && slots < h->cache_lds_slots) slots *= 2;
-    h->mirror_slots = *slots_out = std::min(slots, h->cache_lds_slots);
+    h->journal_states = states;
     h->journal_stale = false;
-    return BSX_OK;
+    return mirror_slots_for(h, slots_out);
 }
+
+void merge_records(MergedTable& merged, const LogRec* recs, size_t n, uint32_t nw);
 
 int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>& d_log, MergedTable* merged,
                         AttractRun& run) {
@@ -517,6 +549,10 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     if (d_log.n < log_cap) HIPCHK(h, d_log.alloc(log_cap));
     P.log = d_log.p;
     P.log_cap = log_cap;
+    // results that are kept may spill from the log into the HBM attractor table (general kernel only: the
+    // lean / pool kernels write at most one record per workgroup and cached attractor)
+    P.table = (merged && !fast && h->table_slots) ? h->d_table.p : nullptr;
+    P.table_mask = h->table_slots ? h->table_slots - 1 : 0;
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (kind == kPassPool) HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
@@ -531,29 +567,149 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
                      kind == kPassPool ? "pool" : fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
                      (unsigned long long)run.ctr.n_stragglers, run.ms, (unsigned long long)run.ctr.wave_iters,
                      (unsigned long long)run.ctr.service_rounds);
+    if (!merged) return BSX_OK;                 // results discarded (discovery): a full log does not matter
+    if (run.ctr.table_inserts) h->table_dirty = true;
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
-    if (!merged) return BSX_OK;
-    const uint64_t n_log = run.ctr.log_cursor;
+    if (run.ctr.table_overflow) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity (device table full)");
+    const uint64_t n_log = std::min<uint64_t>(run.ctr.log_cursor, log_cap);
     std::vector<LogRec> log(n_log);
     if (n_log) HIPCHK(h, hipMemcpy(log.data(), d_log.p, n_log * sizeof(LogRec), hipMemcpyDeviceToHost));
     // merge by key (attract.py:405-455 write_aggregated_attractors_to_db, exact integers)
     const uint32_t nw = h->net.nw;
-    for (const LogRec& r : log) {
-        std::vector<uint32_t> key(r.key, r.key + nw);
-        auto it = merged->find(key);
-        if (it == merged->end()) {
+    merge_records(*merged, log.data(), log.size(), nw);
+    return BSX_OK;
+}
+
+void merge_records(MergedTable& merged, const LogRec* recs, size_t n, uint32_t nw) {
+    for (size_t i = 0; i < n; ++i) {
+        const LogRec& r = recs[i];
+        const Key8 key = key8(r.key);
+        auto it = merged.find(key);
+        if (it == merged.end()) {
             bsx_attr_rec a{};
             for (uint32_t w = 0; w < nw; ++w) a.key[w >> 1] |= (uint64_t)r.key[w] << (32 * (w & 1));
             a.length = r.length;
-            it = merged->emplace(key, a).first;
+            it = merged.emplace(key, a).first;
         }
         bsx_attr_rec& a = it->second;
         a.count += r.count;
         a.sum_l += r.sum_l;
-        const uint64_t lo = a.sum_l2_lo + r.sum_l2;
-        if (lo < a.sum_l2_lo) ++a.sum_l2_hi;
+        const uint64_t lo = a.sum_l2_lo + r.sum_l2_lo;
+        a.sum_l2_hi += r.sum_l2_hi + (lo < a.sum_l2_lo ? 1 : 0);
         a.sum_l2_lo = lo;
     }
+}
+
+void fold_table(MergedTable& into, const MergedTable& from) {
+    for (const auto& kv : from) {
+        auto it = into.find(kv.first);
+        if (it == into.end()) { into.emplace(kv.first, kv.second); continue; }
+        bsx_attr_rec& a = it->second;
+        a.count += kv.second.count;
+        a.sum_l += kv.second.sum_l;
+        const uint64_t lo = a.sum_l2_lo + kv.second.sum_l2_lo;
+        a.sum_l2_hi += kv.second.sum_l2_hi + (lo < a.sum_l2_lo ? 1 : 0);
+        a.sum_l2_lo = lo;
+    }
+}
+
+// ---- cube collapse: which of the `a` lowest initial-state digits can the FIRST update of the
+// block starting at digit value d_lo depend on?  A node's rule, restricted to the block's fixed bits, depends
+// on a free predecessor iff flipping it changes the output for some assignment of the rule's other free
+// inputs; a digit is relevant iff its node is such a predecessor of some node (fixed nodes have constant
+// rules, model.py:45-47).  f(s) is then a function of the relevant digits alone -- exactly, not heuristically.
+struct Cube {
+    uint64_t d_lo;              // first digit value (multiple of 2^a)
+    uint32_t a;                 // log2 of the problems in the block
+    std::vector<uint32_t> rel;  // relevant digits, ascending
+    DevSpace sp;                // enumeration of the relevant digits' assignments
+    uint32_t umask[kMaxW32];    // node bits of the irrelevant free digits
+    uint32_t free_mask[kMaxW32];
+    bool ok = false;            // false: more deposit runs than the kernels take
+};
+
+void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c) {
+    const uint32_t n = h->n_nodes, nw = h->net.nw;
+    c.d_lo = d_lo; c.a = a; c.rel.clear(); c.ok = false;
+    uint32_t base[kMaxW32];
+    for (int w = 0; w < kMaxW32; ++w) { base[w] = h->sp.origin[w]; c.umask[w] = 0; c.free_mask[w] = 0; }
+    std::vector<char> is_free(n, 0), relevant(n, 0);
+    for (uint32_t j = 0; j < h->sp.n_any; ++j) {
+        const uint32_t node = h->h_any[j];
+        if (j < a) { is_free[node] = 1; c.free_mask[node >> 5] |= 1u << (node & 31); }
+        else if ((d_lo >> j) & 1ull) base[node >> 5] |= 1u << (node & 31);
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((h->sp.fixmask[i >> 5] >> (i & 31)) & 1u) continue;
+        const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
+        const uint32_t* preds = h->h_pred_idx.data() + h->h_pred_offsets[i];
+        if (k > (uint32_t)kMaxMuxK) {                    // wide rule: every free input counts (conservative)
+            for (uint32_t j = 0; j < k; ++j) if (is_free[preds[j]]) relevant[preds[j]] = 1;
+            continue;
+        }
+        const uint64_t tt = h->h_tt0[i];
+        uint32_t free_slots = 0, fixed_idx = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+            if (is_free[preds[j]]) free_slots |= 1u << j;
+            else if ((base[preds[j] >> 5] >> (preds[j] & 31)) & 1u) fixed_idx |= 1u << j;
+        }
+        for (uint32_t j = 0; j < k; ++j) {
+            if (!((free_slots >> j) & 1u) || relevant[preds[j]]) continue;
+            const uint32_t others = free_slots & ~(1u << j);
+            uint32_t x = 0;
+            do {                                        // all assignments of the other free inputs
+                const uint32_t idx = fixed_idx | x;
+                if (((tt >> idx) ^ (tt >> (idx | (1u << j)))) & 1ull) { relevant[preds[j]] = 1; break; }
+                x = (x - others) & others;
+            } while (x);
+        }
+    }
+    std::vector<uint32_t> rel_nodes;
+    for (uint32_t j = 0; j < a; ++j) {
+        const uint32_t node = h->h_any[j];
+        if (relevant[node]) { c.rel.push_back(j); rel_nodes.push_back(node); }
+        else c.umask[node >> 5] |= 1u << (node & 31);
+    }
+    // enumeration space of the cube: class index bit q -> node rel_nodes[q], everything else fixed
+    DevSpace sp = h->sp;
+    for (uint32_t w = 0; w < (uint32_t)kMaxW32; ++w) sp.origin[w] = w < nw ? base[w] : 0u;
+    sp.n_any = (uint32_t)rel_nodes.size();
+    sp.identity_any = 0;
+    sp.n_runs = 0;
+    for (int w = 0; w < 4; ++w) sp.first_digits[w] = 0;
+    sp.first_variant = 0;
+    std::vector<uint32_t> plan;
+    for (uint32_t q = 0; q < rel_nodes.size();) {
+        uint32_t len = 1;
+        while (q + len < rel_nodes.size() && rel_nodes[q + len] == rel_nodes[q] + len && ((rel_nodes[q] + len) >> 5) == (rel_nodes[q] >> 5)) ++len;
+        plan.push_back(q | (rel_nodes[q] >> 5) << 8 | (rel_nodes[q] & 31u) << 16);
+        plan.push_back(len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u);
+        q += len;
+    }
+    if (plan.size() > 2 * kMaxDepositRuns) return;
+    sp.n_runs = (uint32_t)(plan.size() / 2);
+    std::copy(plan.begin(), plan.end(), sp.deposit);
+    c.sp = sp;
+    c.ok = true;
+}
+
+// Entries of the HBM attractor table -> `merged`; the table is left empty for the next call.
+int drain_attractor_table(bsx_handle h, MergedTable& merged) {
+    if (!h->table_dirty) return BSX_OK;
+    h->table_dirty = false;
+    DevBuf<unsigned long long> d_cursor;
+    DevBuf<LogRec> d_out;
+    HIPCHK(h, d_cursor.alloc(1));
+    HIPCHK(h, hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, d_out.alloc(h->table_slots));
+    HIPCHK(h, launch_table_drain(h->d_table.p, h->table_slots, d_out.p, h->table_slots, d_cursor.p, h->stream));
+    unsigned long long n = 0;
+    HIPCHK(h, hipMemcpyAsync(&n, d_cursor.p, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<LogRec> recs(n);
+    if (n) HIPCHK(h, hipMemcpy(recs.data(), d_out.p, n * sizeof(LogRec), hipMemcpyDeviceToHost));
+    merged.reserve(merged.size() + n);
+    merge_records(merged, recs.data(), recs.size(), h->net.nw);
     return BSX_OK;
 }
 
@@ -580,11 +736,24 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     if (n_no_attractor) *n_no_attractor = 0;
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
-    if (count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call");
+    // 2^48: sum_l (64 bits) holds count x trajectory length; ranges above 2^32 must collapse into cubes (below)
+    if (count > (1ull << 48)) return fail(h, BSX_ERR_INVALID, "at most 2^48 problems per call");
+    if (per_problem && count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call with per-problem records");
 
     DevBuf<LogRec>& d_log = h->d_log;
     DevBuf<ProblemRec32> d_pp;
     if (per_problem) HIPCHK(h, d_pp.alloc(count));
+    if (h->table_dirty) { MergedTable stale; if (int rc = drain_attractor_table(h, stale)) return rc; }     // a failed call left entries behind
+    {   // HBM attractor table behind the log: two slots per entry of the caller's table (kept zeroed between calls)
+        uint64_t want = 1ull << 16;
+        while (want < 2 * (uint64_t)cap) want *= 2;
+        if (h->table_slots < want) {
+            HIPCHK(h, h->d_table.alloc(want));
+            HIPCHK(h, hipMemset(h->d_table.p, 0, want * sizeof(LogRec)));
+            h->table_slots = want;
+            h->table_dirty = false;
+        }
+    }
 
     AttractParams P{};
     P.net = h->net;
@@ -636,7 +805,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;        // splitmix64 finaliser
                 z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
                 z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-                sample[i] = (uint32_t)((z ^ (z >> 31)) % count);
+                sample[i] = (uint32_t)((z ^ (z >> 31)) % std::min<uint64_t>(count, 1ull << 32));
             }
             DevBuf<uint32_t> d_sample;
             HIPCHK(h, d_sample.upload(sample));
@@ -661,8 +830,10 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     int merge_mode = merge_env ? std::atoi(merge_env) : 2;
     if (merge_mode == 2 && !h->pool_ok) merge_mode = 1;
     const bool merge_lanes = merge_mode != 0;
-    while (use_fast && h->fast_ok && done < count) {
-        const uint64_t tile = std::min<uint64_t>(count - done, h->fast_calibrated ? kLeanTile : kProbeTile);
+    // Lean / pool kernel over [done, seg_end) in tiles; returns with done < seg_end when the fast path gave up.
+    auto run_tiles = [&](uint64_t seg_end) -> int {
+    while (use_fast && h->fast_ok && done < seg_end) {
+        const uint64_t tile = std::min<uint64_t>(seg_end - done, h->fast_calibrated ? kLeanTile : kProbeTile);
         // straggler list: one word per problem, or up to three per class (base + 64-bit member mask) from the
         // pool kernel -- probe tiles get room for every problem as a class of its own, big tiles for a third
         // (more stragglers than that and the lean path is the wrong tool anyway)
@@ -699,16 +870,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             h->fast_ok = false;
             break;
         }
-        for (auto& kv : tile_table) {
-            auto it = merged.find(kv.first);
-            if (it == merged.end()) { merged.emplace(kv.first, kv.second); continue; }
-            bsx_attr_rec& a = it->second;
-            a.count += kv.second.count;
-            a.sum_l += kv.second.sum_l;
-            const uint64_t lo = a.sum_l2_lo + kv.second.sum_l2_lo;
-            a.sum_l2_hi += kv.second.sum_l2_hi + (lo < a.sum_l2_lo ? 1 : 0);
-            a.sum_l2_lo = lo;
-        }
+        fold_table(merged, tile_table);
         account(r);
         uint64_t late = 0;
         if (r.ctr.n_stragglers) {
@@ -748,16 +910,154 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             if (r.ctr.n_stragglers > tile / 2) h->fast_ok = false;          // the cache does not cover this space
         }
     }
-    if (done < count) {
+    if (done < seg_end) {           // not (or no longer) a case for the lean path: the detector takes the rest
         AttractParams Q = P;
         if (done) advance_first(Q.sp, first, done);
-        Q.count = count - done;
+        Q.count = seg_end - done;
+        if (Q.count > (1ull << 32)) return fail(h, BSX_ERR_UNSUPPORTED, "range above 2^32 problems that neither collapses into cubes nor fits the lean path");
         Q.per_problem = per_problem ? d_pp.p + done : nullptr;
         AttractRun r;
         if (int rc = launch_attract_pass(h, Q, kPassGeneral, d_log, &merged, r)) return rc;
         account(r);
+        done = seg_end;
     }
+    return BSX_OK;
+    };
 
+
+    // ---- cube collapse: aligned blocks of >= 2^kCubeMinBits problems are enumerated by their relevant digits
+    // only (see build_cube).  Everything before the first / after the last such block goes through the tiles.
+    const char* cubes_env = std::getenv("BSX_CUBES");                     // "0": off (A/B runs, tests)
+    const bool cubes_ok = use_fast && merge_mode == 2 && !per_problem && h->sp.tp_origin == 0 &&
+                          !(cubes_env && cubes_env[0] == '0') && h->sp.n_any >= kCubeMinBits;
+    auto run_cube = [&](const Cube& c, bool& collapsed) -> int {
+        collapsed = false;
+        const uint32_t nw = h->net.nw, rec_words = nw + 3;
+        const uint32_t r_bits = (uint32_t)c.rel.size();
+        const uint32_t cap_rel32 = (max_t == BSX_T_INF || max_t >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)max_t;
+        const uint64_t list_cap = 1ull << 20;                   // unresolved classes per pass
+        if (h->d_strag.n < list_cap * rec_words) HIPCHK(h, h->d_strag.alloc(list_cap * rec_words));
+        for (int attempt = 0; attempt < 16; ++attempt) {
+            // every cached attractor must be in the mirror, or a class could sit on a cycle nobody recognises
+            uint32_t slots = 0;
+            if (int rc = lean_mirror_slots(h, &slots)) return rc;
+            uint64_t states = 0;
+            for (const CycleRecord& jr : h->h_journal) states += jr.length;
+            if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 8 * states > h->cache_lds_slots) return BSX_OK;
+            AttractParams Q = P;
+            Q.sp = c.sp;
+            Q.count = 1ull << r_bits;
+            Q.merge = 3;
+            Q.cube_shift = c.a - r_bits;
+            for (int w = 0; w < kMaxW32; ++w) { Q.cube_umask[w] = c.umask[w]; Q.cube_free[w] = c.free_mask[w]; }
+            Q.fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
+            Q.per_problem = nullptr;
+            Q.stragglers = h->d_strag.p;
+            Q.stragglers_cap = list_cap * rec_words;
+            AttractRun r;
+            MergedTable pass_table;
+            h->cube_mirror = true;
+            const int rc = launch_attract_pass(h, Q, kPassPool, d_log, &pass_table, r);
+            h->cube_mirror = false;
+            if (rc) return rc;
+            kernel_ms += r.ms; ++launches; steps_exec += r.ctr.steps_exec;
+            if (r.ctr.straggler_overflow) return BSX_OK;                    // too many unresolved classes: not a space for cubes
+            uint64_t extra_none = 0, extra_ref = 0;
+            bool repeat = false;
+            const uint64_t n_unres = r.ctr.straggler_classes;
+            if (n_unres) {
+                // the detector runs from each listed state: a class that was not on a cycle yet gets its exact
+                // result (all members share the rest of the trajectory); one that sits on a cycle needs that
+                // attractor in the cache -- the detector has just published it -- and the pass is repeated
+                std::vector<uint32_t> recs(n_unres * rec_words);
+                HIPCHK(h, hipMemcpy(recs.data(), h->d_strag.p, recs.size() * 4, hipMemcpyDeviceToHost));
+                std::vector<uint32_t> st(n_unres * nw);
+                for (uint64_t i = 0; i < n_unres; ++i) std::copy(recs.begin() + i * rec_words, recs.begin() + i * rec_words + nw, st.begin() + i * nw);
+                DevBuf<uint32_t> d_states;
+                DevBuf<ProblemRec32> d_res;
+                HIPCHK(h, d_states.upload(st));
+                HIPCHK(h, d_res.alloc(n_unres));
+                AttractParams S = P;
+                S.sp = c.sp;
+                S.count = n_unres;
+                S.states = d_states.p;
+                S.per_problem = d_res.p;
+                S.max_len = BSX_T_INF;
+                S.merge = 0;
+                AttractRun rs;
+                if (int rc2 = launch_attract_pass(h, S, kPassGeneral, d_log, nullptr, rs)) return rc2;
+                kernel_ms += rs.ms; ++launches; steps_exec += rs.ctr.steps_exec; limit_hits += rs.ctr.step_limit_hits;
+                std::vector<ProblemRec32> res(n_unres);
+                HIPCHK(h, hipMemcpy(res.data(), d_res.p, n_unres * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
+                for (uint64_t i = 0; i < n_unres && !repeat; ++i) {
+                    const uint32_t* rec = recs.data() + i * rec_words;
+                    const uint64_t t_class = rec[nw], m = ((uint64_t)rec[nw + 2] << 32) | rec[nw + 1];
+                    const ProblemRec32& pr = res[i];
+                    if (!pr.found) { extra_none += m; extra_ref += m * max_t; continue; }      // (finite cap, or the step limit was hit)
+                    if (pr.trajectory_l == 0) { repeat = true; break; }                          // on a cycle: members' mu unknown
+                    const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length;
+                    const bool found = max_t == BSX_T_INF || mu + lam <= max_t;
+                    extra_ref += found ? m * (mu + lam) : m * max_t;
+                    if (!found || lam > max_len) { extra_none += m; continue; }
+                    const Key8 key = key8(pr.key);
+                    auto it = pass_table.find(key);
+                    if (it == pass_table.end()) {
+                        bsx_attr_rec rec_a{};
+                        for (uint32_t w = 0; w < nw; ++w) rec_a.key[w >> 1] |= (uint64_t)pr.key[w] << (32 * (w & 1));
+                        rec_a.length = lam;
+                        it = pass_table.emplace(key, rec_a).first;
+                    }
+                    bsx_attr_rec& e = it->second;
+                    e.count += m;
+                    e.sum_l += m * mu;
+                    const unsigned __int128 sq = (unsigned __int128)(m * mu) * mu + e.sum_l2_lo;
+                    e.sum_l2_lo = (uint64_t)sq;
+                    e.sum_l2_hi += (uint64_t)(sq >> 64);
+                }
+                if (repeat) {
+                    unsigned int known = 0;
+                    HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+                    if (known <= h->h_journal.size()) return BSX_OK;        // the attractor cannot be cached: no cube for this block
+                    continue;                                               // (the detector pass marked the journal stale)
+                }
+            }
+            fold_table(merged, pass_table);
+            n_none += r.ctr.n_none + extra_none;
+            steps_ref += r.ctr.steps_ref + extra_ref;
+            if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] cube 2^%u at digit value %llu: %u relevant digits, %llu classes unresolved by the pool kernel, pass %d\n", c.a, (unsigned long long)c.d_lo, r_bits, (unsigned long long)n_unres, attempt + 1);
+            collapsed = true;
+            return BSX_OK;
+        }
+        return BSX_OK;
+    };
+
+    if (cubes_ok) {
+        // [first, first + count) in digit values; blocks are aligned in the digit value, not in the offset
+        const unsigned __int128 lo = first->init_digits[0], hi = lo + count;
+        const unsigned __int128 unit = (unsigned __int128)1 << kCubeMinBits;
+        unsigned __int128 at = (lo + unit - 1) / unit * unit;
+        const unsigned __int128 body_end = hi / unit * unit;
+        if (at < body_end) {
+            if (int rc = run_tiles((uint64_t)(at - lo))) return rc;
+            while (at < body_end) {
+                uint32_t a_bits = kCubeMaxBits;
+                while (a_bits > kCubeMinBits && ((at & (((unsigned __int128)1 << a_bits) - 1)) != 0 || at + ((unsigned __int128)1 << a_bits) > body_end)) --a_bits;
+                a_bits = std::min(a_bits, h->sp.n_any);
+                Cube c;
+                build_cube(h, (uint64_t)at, a_bits, c);
+                bool collapsed = false;
+                // worth it when the block shrinks at least fourfold (otherwise the tiles do as well and keep member masks)
+                if (c.ok && c.rel.size() + 2 <= a_bits) { if (int rc = run_cube(c, collapsed)) return rc; }
+                const uint64_t block_end = (uint64_t)(at - lo) + (1ull << a_bits);      // (a_bits <= 48: fits)
+                if (collapsed) done = block_end;
+                else if (int rc = run_tiles(block_end)) return rc;
+                at += (unsigned __int128)1 << a_bits;
+            }
+        }
+    }
+    if (int rc = run_tiles(count)) return rc;
+
+    if (int rc = drain_attractor_table(h, merged)) return rc;
     if (merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
     uint32_t i = 0;
     for (auto& kv : merged) table[i++] = kv.second;
@@ -787,6 +1087,224 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     return BSX_OK;
 }
 
+// One k_target launch over [first, first + count): optional dense t_hit, optional histogram.
+static int launch_target_pass(bsx_handle h, const bsx_index* first, uint64_t skip, uint64_t count, uint64_t max_t,
+                              const uint64_t* mask_words, const uint64_t* code_words, uint32_t* d_thit,
+                              unsigned long long* d_hist, uint32_t hist_bins, Counters& ctr, float& ms) {
+    const size_t shmem = h->shmem + (d_hist ? 16 + (size_t)hist_bins * 4 : 0);
+    const Launch L = plan_persistent(h, count, shmem);
+    TargetParams P{};
+    P.net = h->net;
+    P.sp = h->sp;
+    set_first(P.sp, first);
+    if (skip) {                                 // first + skip, carrying into the variant (init_problem adds the offset the same way)
+        unsigned __int128 carry = skip;
+        for (int w = 0; w < 4; ++w) { carry += P.sp.first_digits[w]; P.sp.first_digits[w] = (uint64_t)carry; carry >>= 64; }
+        const uint32_t n_any = h->sp.n_any;
+        if (n_any < 256) {
+            // digits at or above n_any belong to the variant number
+            uint64_t over = 0;
+            for (uint32_t b = n_any; b < 256 && b < n_any + 64; ++b) {
+                over |= ((P.sp.first_digits[b >> 6] >> (b & 63)) & 1ull) << (b - n_any);
+                P.sp.first_digits[b >> 6] &= ~(1ull << (b & 63));
+            }
+            P.sp.first_variant += over;
+        }
+    }
+    P.count = count;
+    P.chunk = L.chunk;
+    P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
+    P.max_t = max_t;
+    for (uint32_t w = 0; w < h->w64; ++w) {
+        P.tmask[2 * w] = (uint32_t)mask_words[w]; P.tcode[2 * w] = (uint32_t)code_words[w];
+        if (2 * w + 1 < (uint32_t)kMaxW32) { P.tmask[2 * w + 1] = (uint32_t)(mask_words[w] >> 32); P.tcode[2 * w + 1] = (uint32_t)(code_words[w] >> 32); }
+    }
+    P.ctr = h->d_ctr.p;
+    P.t_hit = d_thit;
+    P.hist = d_hist;
+    P.hist_bins = d_hist ? hist_bins : 1;
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    return BSX_OK;
+}
+
+// Ordered compaction of t_hit[0..count) -> up to `want` hit records (index order), offsets shifted by `skip`.
+static int compact_hits(bsx_handle h, const uint32_t* d_thit, uint64_t count, uint64_t total_hits, uint64_t skip,
+                        bsx_hit* hits, uint64_t want) {
+    if (!total_hits || !want) return BSX_OK;
+    const uint32_t segs = (uint32_t)((count + 4095) / 4096);
+    DevBuf<uint32_t> d_cnt;
+    DevBuf<uint64_t> d_base;
+    DevBuf<HitRec> d_hits;
+    const uint64_t n_write = std::min(total_hits, want);
+    HIPCHK(h, d_cnt.alloc(segs));
+    HIPCHK(h, d_base.alloc(segs));
+    HIPCHK(h, d_hits.alloc(n_write));
+    HIPCHK(h, launch_compact(d_thit, count, d_cnt.p, nullptr, nullptr, 0, false, h->stream));
+    std::vector<uint32_t> cnt(segs);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), d_cnt.p, segs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<uint64_t> base(segs);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < segs; ++i) { base[i] = run; run += cnt[i]; }
+    if (run != total_hits) return fail(h, BSX_ERR_HIP, "hit compaction count mismatch");
+    HIPCHK(h, hipMemcpyAsync(d_base.p, base.data(), segs * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_compact(d_thit, count, nullptr, d_base.p, d_hits.p, n_write, true, h->stream));    // hits past n_write are dropped
+    static_assert(sizeof(HitRec) == sizeof(bsx_hit), "hit layout");
+    HIPCHK(h, hipMemcpyAsync(hits, d_hits.p, n_write * sizeof(HitRec), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (skip) for (uint64_t i = 0; i < n_write; ++i) hits[i].offset += skip;
+    return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Functional-graph mode (bsx_fgraph.hip): attract over [first, first + count) of a space whose n <= 32 nodes
+// are all 'any', from N = 2^n-sized arrays.  Same results as bsx_run_attract.
+extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                                      uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
+                                      uint64_t* n_no_attractor, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
+    const uint32_t n = h->n_nodes;
+    if (n > 32 || h->sp.n_any != n || !h->sp.identity_any || h->sp.n_fv || h->sp.n_pv || h->sp.tp_origin || h->lut_mode == 2)
+        return fail(h, BSX_ERR_UNSUPPORTED, "functional-graph mode needs n <= 32 nodes, all of them 'any', no variations, no perturbations");
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_out = 0;
+    if (n_no_attractor) *n_no_attractor = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+    if (h->table_dirty) { MergedTable stale; if (int rc = drain_attractor_table(h, stale)) return rc; }
+    {
+        uint64_t want = 1ull << 16;
+        while (want < 2 * (uint64_t)cap) want *= 2;
+        if (h->table_slots < want) {
+            HIPCHK(h, h->d_table.alloc(want));
+            HIPCHK(h, hipMemset(h->d_table.p, 0, want * sizeof(LogRec)));
+            h->table_slots = want;
+        }
+    }
+    const uint64_t N = 1ull << n;
+    const uint32_t cus = (uint32_t)h->prop.multiProcessorCount;
+    const bool capped = max_t != BSX_T_INF;
+    // doubling rounds: 2^rounds must reach every transient that can still be "found" (mu + lambda <= max_t);
+    // without a cap, every transient (mu < N)
+    uint32_t rounds = 0;
+    while (rounds < n && (!capped || (1ull << rounds) <= max_t)) ++rounds;
+    const uint64_t walk_cap = capped ? std::max<uint64_t>(max_t, 1) : (1ull << 22);
+    const uint32_t cand_cap = 1u << 22;
+
+    DevBuf<uint32_t>& succ = h->d_fg_a;
+    DevBuf<uint32_t>& ja = h->d_fg_b;
+    DevBuf<uint32_t>& jb = h->d_fg_c;
+    HIPCHK(h, succ.reserve(N));
+    HIPCHK(h, ja.reserve(std::max<uint64_t>(N, 1024)));         // phase D reuses ja + jb as one array of N pairs
+    HIPCHK(h, jb.reserve(std::max<uint64_t>(N, 1024)));
+    DevBuf<uint32_t> d_bits, d_cand;
+    DevBuf<unsigned int> d_small;       // [0] candidate cursor, [1] cyclic, [2] open, [3] changed
+    HIPCHK(h, d_bits.alloc((N + 31) / 32));
+    HIPCHK(h, hipMemsetAsync(d_bits.p, 0, ((N + 31) / 32) * 4, h->stream));
+    HIPCHK(h, d_cand.alloc(cand_cap));
+    HIPCHK(h, d_small.alloc(4));
+    HIPCHK(h, hipMemsetAsync(d_small.p, 0, 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    uint32_t launches = 0;
+    // A: successor array
+    {
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 4, (N + kBlock - 1) / kBlock));
+        HIPCHK(h, launch_fg_succ((int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, h->net,
+                                 h->sp.fixmask[0], h->sp.fixval[0], N, succ.p));
+        ++launches;
+    }
+    // B: landing points f^(2^rounds)(s)
+    const uint32_t* land = succ.p;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t* out = (r & 1) ? jb.p : ja.p;
+        HIPCHK(h, launch_fg_double(land, out, N, cus, h->stream));
+        land = out;
+        ++launches;
+    }
+    // C: candidates -> cycle states
+    HIPCHK(h, launch_fg_mark(land, N, d_bits.p, cus, h->stream));
+    HIPCHK(h, launch_fg_collect(d_bits.p, (N + 31) / 32, d_cand.p, cand_cap, d_small.p, cus, h->stream));
+    launches += 2;
+    unsigned int small[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(small, d_small.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t n_cand = small[0];
+    if (n_cand > cand_cap) return fail(h, BSX_ERR_UNSUPPORTED, "functional-graph mode: more than 2^22 distinct landing points (use the trajectory path)");
+    uint32_t cyc_slots = 1024;
+    while (cyc_slots < 4 * (uint64_t)n_cand) cyc_slots *= 2;
+    DevBuf<unsigned char> d_cyc;
+    HIPCHK(h, d_cyc.alloc((size_t)(cyc_slots + 1) * fg_cyc_entry_bytes()));
+    HIPCHK(h, hipMemsetAsync(d_cyc.p, 0, (size_t)(cyc_slots + 1) * fg_cyc_entry_bytes(), h->stream));
+    HIPCHK(h, launch_fg_cycles(succ.p, d_cand.p, n_cand, walk_cap, d_cyc.p, cyc_slots - 1, d_small.p + 1, d_small.p + 2, h->stream));
+    ++launches;
+    HIPCHK(h, hipMemcpyAsync(small, d_small.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!capped && small[2]) return fail(h, BSX_ERR_STEP_LIMIT, "functional-graph mode: a cycle longer than 2^22 states (no time cap given)");
+    // D: (entry state, mu) by in-place pointer jumping; pairs live in ja..jb (N x 8 bytes)
+    if ((const void*)(ja.p + N) != (const void*)jb.p) {
+        // the two halves are separate allocations: use a dedicated pair array instead
+        HIPCHK(h, h->d_fg_pair.reserve(N));
+    }
+    unsigned long long* pair = ((const void*)(ja.p + N) == (const void*)jb.p) ? reinterpret_cast<unsigned long long*>(ja.p) : h->d_fg_pair.p;
+    HIPCHK(h, launch_fg_pair_init(succ.p, d_cyc.p, cyc_slots - 1, pair, N, cus, h->stream));
+    ++launches;
+    const uint32_t d_cap = capped ? (uint32_t)std::min<uint64_t>(max_t, 0xFFFFFFFEull) : 0xFFFFFFFEu;
+    for (uint32_t r = 0; r < n + 2; ++r) {
+        HIPCHK(h, hipMemsetAsync(d_small.p + 3, 0, 4, h->stream));
+        HIPCHK(h, launch_fg_pair_jump(pair, N, d_cap, d_small.p + 3, cus, h->stream));
+        ++launches;
+        HIPCHK(h, hipMemcpyAsync(small, d_small.p, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!small[3]) break;
+    }
+    // E: aggregate the requested problems
+    AttractParams P{};
+    P.ctr = h->d_ctr.p;
+    P.table = h->d_table.p;
+    P.table_mask = h->table_slots - 1;
+    const uint64_t first_state = first->init_digits[0];
+    HIPCHK(h, launch_fg_aggregate(pair, d_cyc.p, cyc_slots - 1, first_state, count, capped ? max_t : UINT64_MAX, max_len,
+                                  capped ? max_t : 0, P, cus, h->stream));
+    ++launches;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    Counters ctr{};
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->table_dirty = true;
+    if (ctr.table_overflow) { MergedTable junk; (void)drain_attractor_table(h, junk); return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity"); }
+    MergedTable merged;
+    if (int rc = drain_attractor_table(h, merged)) return rc;
+    if (merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
+    uint32_t i = 0;
+    for (auto& kv : merged) table[i++] = kv.second;
+    *n_out = i;
+    if (n_no_attractor) *n_no_attractor = ctr.n_none;
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = ctr.steps_ref;
+        stats->executed_steps = N;                  // one network update per state of the space
+        stats->kernel_ms = ms;
+        stats->kernel_launches = launches;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    return BSX_OK;
+}
+
 extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                               const uint64_t* mask_words, const uint64_t* code_words, bsx_hit* hits,
                               uint64_t cap, uint64_t* n_hits, bsx_stats* stats) {
@@ -800,60 +1318,15 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
     *n_hits = 0;
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
-
     if (count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call");
-    const Launch L = plan_persistent(h, count, h->shmem);
     DevBuf<uint32_t> d_thit;
     HIPCHK(h, d_thit.alloc(count));
-    TargetParams P{};
-    P.net = h->net;
-    P.sp = h->sp;
-    set_first(P.sp, first);
-    P.count = count;
-    P.chunk = L.chunk;
-    P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
-    P.max_t = max_t;
-    for (uint32_t w = 0; w < h->w64; ++w) {
-        P.tmask[2 * w] = (uint32_t)mask_words[w]; P.tcode[2 * w] = (uint32_t)code_words[w];
-        if (2 * w + 1 < (uint32_t)kMaxW32) { P.tmask[2 * w + 1] = (uint32_t)(mask_words[w] >> 32); P.tcode[2 * w + 1] = (uint32_t)(code_words[w] >> 32); }
-    }
-    P.ctr = h->d_ctr.p;
-    P.t_hit = d_thit.p;
-
-    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, h->shmem, h->stream, P));
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     Counters ctr{};
-    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (int rc = launch_target_pass(h, first, 0, count, max_t, mask_words, code_words, d_thit.p, nullptr, 0, ctr, ms)) return rc;
     const uint64_t total_hits = ctr.log_cursor;
-    if (total_hits > cap) return fail(h, BSX_ERR_TABLE_FULL, "more hits than the caller's capacity");
-    if (total_hits) {
-        // ordered compaction of t_hit[] -> hit list (index order)
-        const uint32_t segs = (uint32_t)((count + 4095) / 4096);
-        DevBuf<uint32_t> d_cnt;
-        DevBuf<uint64_t> d_base;
-        DevBuf<HitRec> d_hits;
-        HIPCHK(h, d_cnt.alloc(segs));
-        HIPCHK(h, d_base.alloc(segs));
-        HIPCHK(h, d_hits.alloc(total_hits));
-        HIPCHK(h, launch_compact(d_thit.p, count, d_cnt.p, nullptr, nullptr, 0, false, h->stream));
-        std::vector<uint32_t> cnt(segs);
-        HIPCHK(h, hipMemcpyAsync(cnt.data(), d_cnt.p, segs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        std::vector<uint64_t> base(segs);
-        uint64_t run = 0;
-        for (uint32_t i = 0; i < segs; ++i) { base[i] = run; run += cnt[i]; }
-        if (run != total_hits) return fail(h, BSX_ERR_HIP, "hit compaction count mismatch");
-        HIPCHK(h, hipMemcpyAsync(d_base.p, base.data(), segs * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, launch_compact(d_thit.p, count, nullptr, d_base.p, d_hits.p, total_hits, true, h->stream));
-        static_assert(sizeof(HitRec) == sizeof(bsx_hit), "hit layout");
-        HIPCHK(h, hipMemcpyAsync(hits, d_hits.p, total_hits * sizeof(HitRec), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+    if (total_hits > cap) return fail(h, BSX_ERR_TABLE_FULL, "more hits than the caller's capacity (bsx_run_target_summary counts without listing)");
+    if (int rc = compact_hits(h, d_thit.p, count, total_hits, 0, hits, cap)) return rc;
     *n_hits = total_hits;
     if (stats) {
         stats->problems = count;
@@ -864,6 +1337,69 @@ extern "C" int bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t cou
         stats->total_ms = now_ms() - t_begin;
     }
     if (ctr.step_limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit");
+    return BSX_OK;
+}
+
+extern "C" int bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                                      const uint64_t* mask_words, const uint64_t* code_words,
+                                      uint64_t* hist, uint32_t hist_bins, bsx_hit* hits, uint64_t cap,
+                                      uint64_t* n_hits, uint64_t* n_listed, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (!mask_words || !code_words || !n_hits || (cap && (!hits || !n_listed)) || (hist_bins && !hist))
+        return fail(h, BSX_ERR_INVALID, "null argument");
+    if (hist_bins > kTargetHistBins) return fail(h, BSX_ERR_INVALID, "at most 2048 histogram bins");
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_hits = 0;
+    if (n_listed) *n_listed = 0;
+    for (uint32_t b = 0; b < hist_bins; ++b) hist[b] = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+    if (count > (1ull << 40)) return fail(h, BSX_ERR_INVALID, "at most 2^40 problems per call");
+
+    DevBuf<unsigned long long> d_hist;
+    if (hist_bins) {
+        HIPCHK(h, d_hist.alloc(hist_bins));
+        HIPCHK(h, hipMemsetAsync(d_hist.p, 0, hist_bins * sizeof(unsigned long long), h->stream));
+    }
+    // The hit list is the first `cap` hits in index order (what -n keeps, simulate.py:163-164): problems are
+    // scanned in pieces with a dense t_hit array until the list is full, the rest of the range is only counted.
+    uint64_t done = 0, listed = 0, total = 0, steps_ref = 0, steps_exec = 0;
+    double kernel_ms = 0.0;
+    uint32_t launches = 0, limit_hits = 0;
+    DevBuf<uint32_t> d_thit;
+    while (done < count) {
+        const bool listing = listed < cap;
+        const uint64_t piece = std::min<uint64_t>(count - done, listing ? std::max<uint64_t>(1ull << 22, 4 * (cap - listed)) : (1ull << 32));
+        if (listing) HIPCHK(h, d_thit.reserve(std::min<uint64_t>(piece, 1ull << 32)));
+        const uint64_t n = listing ? std::min<uint64_t>(piece, d_thit.n) : piece;
+        Counters ctr{};
+        float ms = 0.f;
+        if (int rc = launch_target_pass(h, first, done, n, max_t, mask_words, code_words, listing ? d_thit.p : nullptr,
+                                        hist_bins ? d_hist.p : nullptr, hist_bins, ctr, ms)) return rc;
+        if (listing) {
+            if (int rc = compact_hits(h, d_thit.p, n, ctr.log_cursor, done, hits + listed, cap - listed)) return rc;
+            listed += std::min<uint64_t>(ctr.log_cursor, cap - listed);
+        }
+        total += ctr.log_cursor; steps_ref += ctr.steps_ref; steps_exec += ctr.steps_exec;
+        kernel_ms += ms; ++launches; limit_hits += ctr.step_limit_hits;
+        done += n;
+    }
+    if (hist_bins) HIPCHK(h, hipMemcpy(hist, d_hist.p, hist_bins * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *n_hits = total;
+    if (n_listed) *n_listed = listed;
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = steps_ref;
+        stats->executed_steps = steps_exec;
+        stats->kernel_ms = kernel_ms;
+        stats->kernel_launches = launches;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    if (limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit");
     return BSX_OK;
 }
 

@@ -183,7 +183,10 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
                         my_p = q.next + rank;
                         if (P.offsets) my_p = P.offsets[my_p];
                         exec32 = 0;
-                        if (simple_space) {
+                        if (P.states) {                 // discovery from explicit states (cube passes): no enumeration
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) A[w] = P.states[my_p * NW + w];
+                        } else if (simple_space) {
                             init_problem_simple<NW>(P.sp, my_p, A);
                         } else {
                             Problem<NW> pr;

@@ -13,7 +13,7 @@ constexpr int kTableSlots = 64;             // per-wave attractor table: one slo
 constexpr uint32_t kStepLimit = 1u << 30;   // internal per-trajectory step limit (u32 counters)
 constexpr uint64_t kDigestSeed = 0xCBF29CE484222325ull;
 constexpr uint64_t kDigestPrime = 0x100000001B3ull;
-constexpr uint32_t kMaxDepositRuns = 12;
+constexpr uint32_t kMaxDepositRuns = 32;
 
 // Network tables in HBM (staged into LDS by each workgroup where they fit).
 struct DevNet {
@@ -42,7 +42,7 @@ struct DevSpace {
     // run r: digits [src, src + len) -> bits [shift, shift + len) of word `word`;
     // deposit[2r] = src | word << 8 | shift << 16, deposit[2r + 1] = ((1 << len) - 1)
     uint32_t n_runs;                // 0 = no run plan (identity spaces do not need one)
-    uint32_t deposit[2 * 12];
+    uint32_t deposit[2 * kMaxDepositRuns];
     uint32_t n_fv;
     uint32_t n_pv;
     uint32_t tp_origin;             // last origin perturbation time (0 = none)
@@ -60,11 +60,12 @@ struct DevSpace {
 struct LogRec {
     uint32_t key[kMaxW32];
     uint32_t length;
-    uint32_t count;
+    uint32_t pad;
+    uint64_t count;             // 64 bits: one class of a cube pass can stand for 2^40 problems
     uint64_t sum_l;
-    uint64_t sum_l2;
+    uint64_t sum_l2_lo, sum_l2_hi;
 };
-static_assert(sizeof(LogRec) == 56, "LogRec layout");
+static_assert(sizeof(LogRec) == 72, "LogRec layout");
 
 struct ProblemRec32 {           // per-problem output, device layout
     uint32_t key[kMaxW32];
@@ -87,6 +88,9 @@ struct Counters {               // zeroed before every launch
     unsigned long long straggler_classes;   // lean kernel with merging: (group, member mask) pairs in the straggler list
     unsigned int straggler_overflow;
     unsigned int pad;
+    unsigned long long table_inserts;   // records that went to the HBM attractor table (the log was full)
+    unsigned int table_overflow;        // ... and did not find a slot there
+    unsigned int pad3;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic
 };
@@ -139,6 +143,11 @@ struct AttractParams {
     Counters* ctr;
     LogRec* log;
     uint64_t log_cap;
+    // HBM attractor table behind the log (store_attractor's dict, attract.py:374-402, for spaces with very
+    // many attractors): open addressing over LogRec slots, LogRec::pad = slot state (0 empty, 1 being
+    // written, 2 ready).  Null in passes whose results are discarded.
+    LogRec* table;
+    uint64_t table_mask;        // slots - 1 (power of two)
     ProblemRec32* per_problem;  // nullable, indexed by problem offset
     CycleCache cc;
     const uint32_t* offsets;    // nullable: work item i is problem offsets[i] (straggler pass)
@@ -147,7 +156,18 @@ struct AttractParams {
     uint32_t fast_steps;        // FAST phase length
     uint32_t pad;               // lean kernel: service-lane override (0 = default)
     uint32_t merge;             // lean kernel: merge sibling trajectories that reach the same state (stragglers become pairs)
-    uint32_t pad2;
+                                // pool kernel: 1 member masks, 2 member counts, 3 member counts over a cube (below)
+    // Cube pass of the pool kernel (DESIGN.md "cube collapse"): the work items are not problems but the
+    // 2^r assignments of the RELEVANT digits of an aligned block of 2^a problems -- digits the first update
+    // does not depend on are left at 0 and every class starts with 2^(a-r) members (cube_shift = a - r).
+    // cube_umask = node bits of those irrelevant free digits: a member whose s(0) is itself a cycle state
+    // differs from its class representative only there.  cube_base/cube_free: the block's fixed bits and the
+    // mask of all its free node bits (which cached cycle states lie inside the block).
+    uint32_t cube_shift;
+    uint32_t cube_umask[kMaxW32];
+    uint32_t cube_free[kMaxW32];
+    // general kernel, discovery from explicit states: work item i starts at states[i * nw ..] (no enumeration)
+    const uint32_t* states;
 };
 
 struct HitRec { uint64_t offset; uint64_t t; };
@@ -162,8 +182,12 @@ struct TargetParams {
     uint32_t tmask[kMaxW32];
     uint32_t tcode[kMaxW32];
     Counters* ctr;
-    uint32_t* t_hit;            // [count] first hit time per problem, 0xFFFFFFFF = target not reached
+    uint32_t* t_hit;            // nullable: [count] first hit time per problem, 0xFFFFFFFF = target not reached
+    unsigned long long* hist;   // nullable: [hist_bins] hits by first-hit time, last bin = that time or later
+    uint32_t hist_bins;         // <= kTargetHistBins (the workgroups count in LDS first)
+    uint32_t pad;
 };
+constexpr uint32_t kTargetHistBins = 2048;
 
 struct SimParams {
     DevNet net;

@@ -61,6 +61,8 @@ struct bsx_engine {
     std::vector<bsx::CycleRecord> h_journal;
     bool journal_stale = true;  // a general-kernel pass (the only writer of the journal) ran since h_journal was read
     uint32_t mirror_slots = 64;
+    uint64_t journal_states = 0;    // cycle states of the journal records the lean / pool mirror takes
+    bool cube_mirror = false;       // the next pool pass is a cube pass (mirror sized for representative entries)
     uint32_t fast_steps = 0;    // lean kernel: steps without a cached cycle state before a problem is handed over (0 = default)
     bool fast_calibrated = false;
     uint32_t cache_lds_slots = 0;
@@ -70,6 +72,9 @@ struct bsx_engine {
 
     // scratch kept across calls (grow-only): hipMalloc / hipFree per call cost ~1 ms of a 16 ms step
     bsx::DevBuf<bsx::LogRec> d_log;
+    bsx::DevBuf<bsx::LogRec> d_table;   // HBM attractor table behind the log (all slots zero between calls)
+    uint64_t table_slots = 0;
+    bool table_dirty = false;
     bsx::DevBuf<uint32_t> d_strag;
     bsx::DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
 
@@ -77,6 +82,7 @@ struct bsx_engine {
     std::vector<uint32_t> h_pred_offsets, h_pred_idx;
     std::vector<uint64_t> h_tt0;        // first table word of every node (all of it when k <= 6)
     std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
+    std::vector<uint32_t> h_any;        // 'any' nodes in digit order (cube collapse: relevant-digit analysis)
 
     // problem space
     bool have_space = false;
@@ -87,6 +93,10 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
 
     bsx::DevBuf<bsx::Counters> d_ctr;
+
+    // functional-graph mode (bsx_fgraph.hip): N-sized arrays, kept between calls (grow-only)
+    bsx::DevBuf<uint32_t> d_fg_a, d_fg_b, d_fg_c;
+    bsx::DevBuf<unsigned long long> d_fg_pair;
 
     // RCCL communicator of this handle's rank (bsx_comm.cpp); librccl is loaded on first use
     void* comm = nullptr;       // ncclComm_t

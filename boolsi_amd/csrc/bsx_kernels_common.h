@@ -454,8 +454,63 @@ struct TableSlot {
 };
 
 template <int NW>
+__device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]);
+
+// HBM attractor table: insert-or-add by key.  One loop, every exit inside the loop body: a lane that wins a
+// slot finishes writing it in the same iteration in which its wave-mates find it busy, so spinning lanes of
+// the same wave cannot starve the writer.
+template <int NW>
+__device__ __noinline__ void table_insert(const AttractParams& P, const uint32_t (&key)[NW], uint32_t length,
+                                          uint64_t count, uint64_t sl, uint64_t sl2, uint64_t sl2_hi) {
+    uint32_t hsh = hash_state<NW>(key) * 0x9E3779B1u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) hsh = (hsh ^ key[w]) * 0x85EBCA6Bu;
+    uint64_t at = (uint64_t)(hsh ^ (hsh >> 15)) & P.table_mask;
+    uint32_t probes = 0, spins = 0;
+    bool done = false;
+    while (!done) {
+        LogRec* e = P.table + at;
+        uint32_t st = __hip_atomic_load(&e->pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        bool mine = false;
+        if (st == 0u) {
+            st = atomicCAS(&e->pad, 0u, 1u);
+            if (st == 0u) {
+#pragma unroll
+                for (int w = 0; w < kMaxW32; ++w) e->key[w] = w < NW ? key[w < NW ? w : 0] : 0u;
+                e->length = length;
+                __hip_atomic_store(&e->pad, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                mine = true;
+            }
+        }
+        if (!mine && st == 1u) {                // somebody is writing the key: look again (bounded)
+            if (++spins > (1u << 20)) { atomicOr(&P.ctr->table_overflow, 2u); done = true; }
+            continue;
+        }
+        bool same = mine;
+        if (!mine) {                            // st == 2: ready
+            uint32_t d = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) d |= __hip_atomic_load(&e->key[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ key[w];
+            same = d == 0;
+        }
+        if (same) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&e->count), (unsigned long long)count);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&e->sum_l), (unsigned long long)sl);
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&e->sum_l2_lo), (unsigned long long)sl2);
+            const unsigned long long up = sl2_hi + ((old + sl2 < old) ? 1ull : 0ull);
+            if (up) atomicAdd(reinterpret_cast<unsigned long long*>(&e->sum_l2_hi), up);
+            done = true;
+        } else {
+            at = (at + 1) & P.table_mask;
+            spins = 0;
+            if (++probes > 4096u) { atomicOr(&P.ctr->table_overflow, 1u); done = true; }
+        }
+    }
+}
+
+template <int NW>
 __device__ __forceinline__ void log_append(const AttractParams& P, const uint32_t (&key)[NW], uint32_t length,
-                                           uint32_t count, uint64_t sl, uint64_t sl2) {
+                                           uint64_t count, uint64_t sl, uint64_t sl2, uint64_t sl2_hi = 0) {
     const unsigned long long at = atomicAdd(&P.ctr->log_cursor, 1ull);
     if (at < P.log_cap) {
         LogRec r;
@@ -463,8 +518,11 @@ __device__ __forceinline__ void log_append(const AttractParams& P, const uint32_
         for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) r.key[w] = key[w];
-        r.length = length; r.count = count; r.sum_l = sl; r.sum_l2 = sl2;
+        r.length = length; r.pad = 0; r.count = count; r.sum_l = sl; r.sum_l2_lo = sl2; r.sum_l2_hi = sl2_hi;
         P.log[at] = r;
+    } else if (P.table) {                       // log full: straight into the HBM table
+        atomicAdd(&P.ctr->table_inserts, 1ull);
+        table_insert<NW>(P, key, length, count, sl, sl2, sl2_hi);
     } else {
         atomicOr(&P.ctr->log_overflow, 1u);
     }
@@ -552,7 +610,9 @@ __device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]) {
 // mostly non-cycle states that was the case in four wave iterations out of five.
 constexpr int kCacheHeaderWords = 4;
 constexpr uint32_t kTagCont = 0x80000000u;
-constexpr uint32_t kTagMask = 0x7FFFFFFFu;
+constexpr uint32_t kTagRep = 0x40000000u;      // pool kernel, cube pass: entry is the class representative of a cycle
+                                               // state (its irrelevant free bits cleared); it counts at t = 0 only
+constexpr uint32_t kTagMask = 0x3FFFFFFFu;
 
 // One probe: loads the whole entry with no control flow in between (so the reads are issued together
 // with whatever else the caller has in flight) and classifies it.

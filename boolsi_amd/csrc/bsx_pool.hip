@@ -28,6 +28,15 @@ namespace bsx {
 // their masks: per-wave hash slots + ds_bpermute compare, as in the lean kernel) and the survivors are
 // appended to the pool.  Nothing but the accumulators lives in registers across iterations, so there is
 // no per-lane state machine and no service round.
+// Cube pass (P.merge == 3, DESIGN.md "cube collapse"): the first update of an aligned block of 2^a consecutive
+// problems depends only on the RELEVANT free digits (the host finds them from the truth tables restricted to
+// the block's fixed bits), so the fresh stage enumerates the 2^r assignments of those digits instead of the
+// 2^a problems and every class starts with 2^(a-r) members (64-bit member counts).  A member whose s(0) is
+// itself a cycle state (mu = 0) differs from its class representative only in irrelevant bits: the mirror
+// gets a second entry per cached cycle state inside the block -- the state with those bits cleared, flagged
+// kTagRep -- which a t = 0 probe of the representative hits (at most one member per class can be a cycle
+// state: two would share their successor).  Classes that are still unresolved at the step limit are listed
+// with their state for the host (discovery of uncached attractors, then the pass is repeated).
 // Workgroup = 12 waves sharing one LUT and cache mirror: with n = 64 that is 39 KiB + 12 x 3.3 KiB of LDS,
 // so two workgroups fit a CU = 6 waves per SIMD, 3 from each (with 8-wave workgroups and 128-class rings
 // it was 4).  The kernel is bound by the latency of its dependent LDS round trips, so waves matter.
@@ -40,7 +49,22 @@ constexpr uint32_t kPoolSlots = 128;            // merge slots per wave (one-byt
 constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // state, group base, members lo/hi, time
 constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
 
-template <int NW, int K, int LM>
+// OR the digits of `d` into `s` along the deposit plan (init_problem_simple without the origin).  With a
+// wave-uniform `d` this is scalar work.
+template <int NW>
+__device__ __forceinline__ void deposit_runs(const DevSpace& sp, uint64_t d, uint32_t (&s)[NW]) {
+    for (uint32_t r = 0; r < sp.n_runs; ++r) {
+        const uint32_t desc = sp.deposit[2 * r], mask = sp.deposit[2 * r + 1];
+        const uint32_t piece = ((uint32_t)(d >> (desc & 63u)) & mask) << ((desc >> 16) & 31u);
+        const uint32_t word = (desc >> 8) & 7u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s[w] |= (word == (uint32_t)w) ? piece : 0u;
+    }
+}
+
+// CUBE = true: the cube-pass build of the kernel (P.merge == 3): member counts only, no member masks, no
+// per-problem records; kept apart so that neither build carries the other's registers.
+template <int NW, int K, int LM, bool CUBE>
 __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
@@ -51,7 +75,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     // P.merge == 2: classes carry a member COUNT instead of the member mask, so classes of different groups
     // may merge too (same state, same time); a class that would have to go back to the general kernel cannot
     // be taken apart again, so it raises the abort flag and the host repeats the tile with member masks.
-    const bool counting = P.merge == 2;                     // uniform
+    const bool counting = CUBE || P.merge >= 2;             // uniform
+    constexpr bool cube = CUBE;                             // work items are relevant-digit assignments
     const int32_t fast_steps = (int32_t)P.fast_steps;
     const uint32_t cmask = P.cc.lds_slots - 1;
     constexpr int S = CacheLayout<NW>::kStride;
@@ -62,12 +87,14 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     //      [per wave: pool records | 64 x 8 B member accumulators | 256 one-byte lane ids]
     uint32_t* lc = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);
     const uint32_t lc_words = kCacheHeaderWords + P.cc.lds_slots * S;
-    unsigned long long* acc_sl2 = reinterpret_cast<unsigned long long*>(lc + ((lc_words + 1u) & ~1u));
-    unsigned long long* acc_sl = acc_sl2 + kAccs;
-    unsigned int* acc_cnt = reinterpret_cast<unsigned int*>(acc_sl + kAccs);
-    uint32_t* lamtab = acc_cnt + kAccs;
+    unsigned long long* acc_sl2 = reinterpret_cast<unsigned long long*>(lc + ((lc_words + 1u) & ~1u));     // 128-bit sum l^2: low,
+    unsigned long long* acc_sl2h = acc_sl2 + kAccs;                                                         // high
+    unsigned long long* acc_sl = acc_sl2h + kAccs;
+    unsigned long long* acc_cnt = acc_sl + kAccs;
+    uint32_t* lamtab = reinterpret_cast<uint32_t*>(acc_cnt + kAccs);
     uint32_t* keytab = lamtab + kAccs;
     constexpr uint32_t kWaveWords = kPoolCap * R + 128 + kPoolSlots / 4;
+    static_assert(kAccs % 2 == 0 && kWaveWords % 2 == 0, "64-bit LDS atomics need 8-byte aligned tables");
     uint32_t* wave_base = keytab + ((kAccs * NW + 1u) & ~1u) + wave * kWaveWords;
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
@@ -81,7 +108,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; any_fixed |= fm0[w]; }
     const bool has_fixed = any_fixed != 0;                  // uniform
     for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
-    for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl2h[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
     dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -99,11 +126,41 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         }
     }
     __syncthreads();
+    // cube pass: cached cycle states inside the block get a second mirror entry, their class representative
+    if (cube && threadIdx.x == 0) {
+        uint32_t n_in = 0;
+        for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
+            const uint32_t* e = cbase + sl * S;
+            const uint32_t tw = e[NW];
+            if ((tw & kTagMask) == 0 || (tw & kTagRep)) continue;
+            uint32_t rep[NW], key[NW], outside = 0, differs = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t st = e[w];
+                outside |= (st ^ P.sp.origin[w]) & ~P.cube_free[w];
+                rep[w] = st & ~P.cube_umask[w];
+                differs |= rep[w] ^ st;
+                key[w] = e[NW + 2 + w];
+            }
+            if (outside) continue;
+            ++n_in;
+            if (differs) cache_insert_lds<NW>(lc, cmask, rep, e[NW + 1], key, (tw & kTagMask) | kTagRep);
+        }
+        lc[1] = n_in;
+    }
+    __syncthreads();
+    const bool t0_lookup = cube && __builtin_amdgcn_readfirstlane(lc[1]) != 0;     // uniform: some member may have mu = 0
+    // cube pass: a wave's 64 classes differ in the six lowest relevant digits only; where those land in the
+    // state is the same in every iteration, the rest of the class index is wave-uniform (scalar deposit)
+    uint32_t lane_part[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) lane_part[w] = 0;
+    if constexpr (cube) deposit_runs<NW>(P.sp, (uint64_t)lane, lane_part);
 
     const uint32_t cap_rel = (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)(P.max_t - tp);
 
-    unsigned long long extra_ref = 0;
-    uint32_t nexec = 0, n_none = 0, n_capfail = 0;
+    unsigned long long extra_ref = 0, n_none = 0, n_capfail = 0;
+    uint32_t nexec = 0;
     WaveQueue q{0, 0, true};
     uint32_t head = 0, count = 0;                           // pool ring (uniform)
 #ifdef BSX_DIAG
@@ -112,7 +169,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 
     // is `s` a cached cycle state?  -> the entry's tag word (0 = no); `hfull` = the state's hash
     uint32_t hit_len = 0;                   // NW <= 2: the entry's length word comes with the probe's 16-byte read
-    auto probe = [&](const uint32_t (&s)[NW], uint32_t& hfull) -> uint32_t {
+    // (representative entries of a cube pass count only for the t = 0 probe: `reps`)
+    auto probe = [&](const uint32_t (&s)[NW], uint32_t& hfull, bool reps = false) -> uint32_t {
+        const uint32_t ignore = reps ? 0u : kTagRep;
         hfull = hash_state<NW>(s);
         uint32_t h = hfull & cmask;
         const uint32_t* e = cbase + h * S;
@@ -130,7 +189,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             for (int w = 0; w < NW; ++w) d |= e[w] ^ s[w];
             et = e[NW];
         }
-        bool hit = (d == 0) & (et != 0);
+        bool hit = (d == 0) & (et != 0) & ((et & ignore) == 0);
         bool walking = (et >> 31) != 0 && !hit;
         if (__builtin_expect(__ballot(walking) != 0, 0)) {
             while (walking) {
@@ -140,12 +199,36 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
                 for (int w = 0; w < NW; ++w) d2 |= f[w] ^ s[w];
                 const uint32_t ft = f[NW];
-                const bool here = (d2 == 0) & (ft != 0);
+                const bool here = (d2 == 0) & (ft != 0) & ((ft & ignore) == 0);
                 if (here) { hit = true; et = ft; hit_len = f[NW + 1]; }
                 walking = (ft >> 31) != 0 && !here;
             }
         }
         return hit ? et : 0u;
+    };
+
+    // m members end on the cycle state with tag word `tagw` at time mu (attract.py:291-298 for each of them)
+    auto account = [&](uint32_t tagw, unsigned long long m, uint32_t mu, uint32_t lam, bool& keep_out) {
+        const uint32_t tg = tagw & kTagMask, traj = tp + mu;
+        const bool found = mu <= cap_rel && lam <= cap_rel - mu;
+        const bool keep = found && (uint64_t)lam <= P.max_len;              // attract.py:294
+        keep_out = keep;
+        if (__builtin_expect(!keep, 0)) {
+            n_none += m;
+            n_capfail += found ? 0ull : m;
+            extra_ref += found ? m * (traj + lam) : 0ull;                   // model.py:201
+        } else {
+            // Straight into the workgroup's accumulators: a wave resolves less than one class per
+            // iteration on average (64 problems end as one or two classes), so the LDS atomics do not
+            // queue up, and no per-lane sums have to be carried in registers.
+            const unsigned long long wl = m * traj;                         // m < 2^49, traj < 2^13
+            const unsigned long long lo = wl * traj, hi = __umul64hi(wl, (unsigned long long)traj);
+            atomicAdd(&acc_cnt[tg - 1], m);
+            atomicAdd(&acc_sl[tg - 1], wl);
+            const unsigned long long old = atomicAdd(&acc_sl2[tg - 1], lo);
+            const unsigned long long up = hi + ((old + lo < old) ? 1ull : 0ull);
+            if (up) atomicAdd(&acc_sl2h[tg - 1], up);
+        }
     };
 
     for (;;) {
@@ -190,11 +273,37 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             const uint32_t n = avail < 64u ? (uint32_t)avail : 64u;
             live = lane < n;
             base = (uint32_t)q.next;
-            init_problem_simple<NW>(P.sp, q.next + lane, A);
-            mlo = counting ? 1u : (lane < 32u ? 1u << lane : 0u);
-            mhi = counting || lane < 32u ? 0u : 1u << (lane - 32u);
+            if constexpr (cube) {                           // q.next is a multiple of 64 and the class index starts at 0
+                uint32_t u[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) u[w] = P.sp.origin[w];
+                deposit_runs<NW>(P.sp, q.next, u);
+#pragma unroll
+                for (int w = 0; w < NW; ++w) A[w] = u[w] | lane_part[w];
+            } else {
+                init_problem_simple<NW>(P.sp, q.next + lane, A);
+            }
+            if (counting) {                                 // (mlo, mhi) = 64-bit member count
+                const unsigned long long members = 1ull << (cube ? P.cube_shift : 0u);
+                mlo = (uint32_t)members; mhi = (uint32_t)(members >> 32);
+            } else {                                        // (mlo, mhi) = member mask
+                mlo = lane < 32u ? 1u << lane : 0u;
+                mhi = lane < 32u ? 0u : 1u << (lane - 32u);
+            }
             t = -(int32_t)tp;
             q.next += n;
+            if (t0_lookup) {
+                // is a member of this class itself a cycle state (mu = 0)?  Its representative entry says so.
+                uint32_t h0;
+                const uint32_t et0 = live ? probe(A, h0, true) : 0u;
+                if (et0) {
+                    bool kept;
+                    account(et0, 1ull, 0u, NW <= 2 ? hit_len : lamtab[(et0 & kTagMask) - 1], kept);
+                    const unsigned long long left = (((unsigned long long)mhi << 32) | mlo) - 1ull;
+                    mlo = (uint32_t)left; mhi = (uint32_t)(left >> 32);
+                    live = left != 0;
+                }
+            }
 #ifdef BSX_DIAG
             ++dbg_fresh;
 #endif
@@ -213,7 +322,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             if (has_warmup) et = t >= 0 ? et : 0u;          // states before T_p do not count
             // s(T_p) = s(0) itself may be a cycle state (mu = 0).  It is only looked up when s(1) is one --
             // a successor of a cycle state is a cycle state -- instead of for every fresh problem.
-            if (!has_warmup && __ballot(et != 0 && t == 1)) {
+            if (!has_warmup && !cube && __ballot(et != 0 && t == 1)) {
                 if (et != 0 && t == 1) {
                     uint32_t h0;
                     const uint32_t len1 = hit_len;
@@ -238,13 +347,13 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         const uint32_t w = cand ? (uint32_t)dd_ids[slot] : lane;
 
         // ---- resolved classes: every member has mu = t
-        const uint32_t m = counting ? mlo : (uint32_t)(__popc(mlo) + __popc(mhi));
+        const unsigned long long m = counting ? (((unsigned long long)mhi << 32) | mlo) : (unsigned long long)(__popc(mlo) + __popc(mhi));
         if (live && res != 0) {
-            const uint32_t tg = res & kTagMask, mu = (uint32_t)t, traj = tp + mu;
+            const uint32_t tg = res & kTagMask;
             const uint32_t lam = NW <= 2 ? hit_len : lamtab[tg - 1];
-            const bool found = mu <= cap_rel && lam <= cap_rel - mu;
-            const bool keep = found && (uint64_t)lam <= P.max_len;          // attract.py:294
-            if (P.per_problem) {
+            bool keep;
+            account(res, m, (uint32_t)t, lam, keep);
+            if (!cube && P.per_problem) {
                 ProblemRec32 r;
 #pragma unroll
                 for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
@@ -252,30 +361,26 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
                     for (int w = 0; w < NW; ++w) r.key[w] = keytab[(tg - 1) * NW + w];
                 }
-                r.length = keep ? lam : 0; r.trajectory_l = keep ? traj : 0; r.found = keep; r.pad = 0;
+                r.length = keep ? lam : 0; r.trajectory_l = keep ? tp + (uint32_t)t : 0; r.found = keep; r.pad = 0;
                 for (uint32_t left = mlo; left; left &= left - 1) P.per_problem[base + (uint32_t)__builtin_ctz(left)] = r;
                 for (uint32_t left = mhi; left; left &= left - 1) P.per_problem[base + 32u + (uint32_t)__builtin_ctz(left)] = r;
-            }
-            if (__builtin_expect(!keep, 0)) {
-                n_none += m;
-                n_capfail += found ? 0u : m;
-                extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
-            } else {
-                // Straight into the workgroup's accumulators: a wave resolves less than one class per
-                // iteration on average (64 problems end as one or two classes), so the LDS atomics do not
-                // queue up, and no per-lane sums have to be carried in registers.
-                const uint32_t wl = __umul24(m, traj);      // m <= 64, traj < 2^14
-                atomicAdd(&acc_cnt[tg - 1], m);
-                atomicAdd(&acc_sl[tg - 1], (unsigned long long)wl);
-                atomicAdd(&acc_sl2[tg - 1], (unsigned long long)wl * traj);
             }
         }
         // ---- classes past the FAST length go back as (group base, member mask)
         if (live && res == 0 && t >= fast_steps) {
-            if (counting) atomicOr(&P.ctr->straggler_overflow, 2u);         // members unknown: the host repeats the tile
-            atomicAdd(&P.ctr->n_stragglers, (unsigned long long)m);
+            if (counting && !cube) atomicOr(&P.ctr->straggler_overflow, 2u);    // members unknown: the host repeats the tile
+            atomicAdd(&P.ctr->n_stragglers, m);
             const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
-            if (3 * at + 2 < P.stragglers_cap) { P.stragglers[3 * at] = base; P.stragglers[3 * at + 1] = mlo; P.stragglers[3 * at + 2] = mhi; }
+            if (cube) {
+                // (state, t, member count): the host runs the detector from the state; an attractor it did not
+                // know yet means the pass is repeated, otherwise the class simply ran past the time cap
+                constexpr uint32_t kRec = NW + 3;
+                if (kRec * (at + 1) <= P.stragglers_cap) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) P.stragglers[kRec * at + w] = A[w];
+                    P.stragglers[kRec * at + NW] = (uint32_t)t; P.stragglers[kRec * at + NW + 1] = mlo; P.stragglers[kRec * at + NW + 2] = mhi;
+                } else atomicOr(&P.ctr->straggler_overflow, 1u);
+            } else if (3 * at + 2 < P.stragglers_cap) { P.stragglers[3 * at] = base; P.stragglers[3 * at + 1] = mlo; P.stragglers[3 * at + 2] = mhi; }
             else atomicOr(&P.ctr->straggler_overflow, 1u);
         }
 
@@ -291,7 +396,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             if (__ballot(same)) {
                 if (same) {
                     if (counting) {
-                        atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
+                        atomicAdd((unsigned long long*)(__attribute__((address_space(3))) unsigned long long*)&dd_acc[2 * w],
+                                  ((unsigned long long)mhi << 32) | mlo);
                     } else {
                         if (mlo) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
                         if (mhi) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w + 1], mhi);
@@ -303,8 +409,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 if (cand) {
                     const uint32_t glo = dd_acc[2 * lane], ghi = dd_acc[2 * lane + 1];
                     if (glo | ghi) {
-                        mlo = counting ? mlo + glo : mlo | glo;
-                        mhi |= ghi;
+                        if (counting) {
+                            const unsigned long long sum = (((unsigned long long)mhi << 32) | mlo) + (((unsigned long long)ghi << 32) | glo);
+                            mlo = (uint32_t)sum; mhi = (uint32_t)(sum >> 32);
+                        } else { mlo |= glo; mhi |= ghi; }
                         dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
                     }
                 }
@@ -342,39 +450,54 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     // ---- epilogue: workgroup accumulators -> one log record per attractor and workgroup
     __syncthreads();
     for (uint32_t a = threadIdx.x; a < kAccs; a += blockDim.x) {
-        const uint32_t cn = acc_cnt[a];
+        const unsigned long long cn = acc_cnt[a];
         if (!cn) continue;
         uint32_t k[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) k[w] = keytab[a * NW + w];
         const unsigned long long sl = acc_sl[a];
-        log_append<NW>(P, k, lamtab[a], cn, sl, acc_sl2[a]);
-        extra_ref += sl + (unsigned long long)cn * lamtab[a];                   // + lambda each (model.py:201)
+        log_append<NW>(P, k, lamtab[a], cn, sl, acc_sl2[a], acc_sl2h[a]);
+        extra_ref += sl + cn * lamtab[a];                                       // + lambda each (model.py:201)
     }
 #ifdef BSX_DIAG
     if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_fresh); }
 #endif
-    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), (int)lane);
+    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : n_capfail * P.max_t), (int)lane);
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, (int)lane);
-    wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, (int)lane);
+    wave_atomic_add(&P.ctr->n_none, n_none, (int)lane);
 }
 
 template <int NW, int K>
+static const void* pool_kernel_for(int lut_mode, bool cube) {
+    const void* fn = nullptr;
+    if (cube) {
+        if (lut_mode == kLutLdsByte) fn = (const void*)k_attract_pool<NW, K, kLutLdsByte, true>;
+        else if (lut_mode == kLutGlobal) fn = (const void*)k_attract_pool<NW, K, kLutGlobal, true>;
+        else if constexpr (NW >= 4) { if (lut_mode == kLutLdsNibble) fn = (const void*)k_attract_pool<NW, K, kLutLdsNibble, true>; }
+    } else {
+        if (lut_mode == kLutLdsByte) fn = (const void*)k_attract_pool<NW, K, kLutLdsByte, false>;
+        else if (lut_mode == kLutGlobal) fn = (const void*)k_attract_pool<NW, K, kLutGlobal, false>;
+        else if constexpr (NW >= 4) { if (lut_mode == kLutLdsNibble) fn = (const void*)k_attract_pool<NW, K, kLutLdsNibble, false>; }
+    }
+    return fn;
+}
+template <int NW, int K>
 static hipError_t launch_pool_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    const void* fn;
-    BSX_KERNEL_FOR_MODE(k_attract_pool, NW, K, lut_mode, fn);
+    const void* fn = pool_kernel_for<NW, K>(lut_mode, P.merge == 3);
     if (!fn) return hipErrorInvalidValue;
     void* args[] = {const_cast<AttractParams*>(&P)};
     return hipLaunchKernel(fn, grid, dim3(kPoolBlock), args, shmem, st);
 }
 template <int NW, int K>
 static hipError_t configure_pool_nk(int lut_mode, dim3, size_t shmem, hipStream_t, int& blocks_per_cu) {
-    const void* fn;
-    BSX_KERNEL_FOR_MODE(k_attract_pool, NW, K, lut_mode, fn);
-    if (!fn) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kPoolBlock, shmem);
+    for (int cube = 0; cube < 2; ++cube) {
+        const void* fn = pool_kernel_for<NW, K>(lut_mode, cube != 0);
+        if (!fn) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        if (!cube) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kPoolBlock, shmem); if (e != hipSuccess) return e; }
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
@@ -389,7 +512,7 @@ hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int
 
 // bytes of LDS behind the cache mirror: per-attractor tables + per-wave pool, accumulators and id slots
 size_t pool_extra_bytes(uint32_t nw) {
-    const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 4 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16;
+    const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 8 + 8 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16;
     const size_t per_wave = ((size_t)kPoolCap * pool_rec_words(nw) + 128 + kPoolSlots / 4) * 4;
     return tables + (size_t)kPoolWaves * per_wave;
 }

@@ -15,6 +15,8 @@ __device__ __forceinline__ bool target_hit(const uint32_t (&s)[NW], const uint32
 // target: stop at the first t >= T_p with (state & mask) == code; a trajectory that closes its cycle
 // (or hits max_t) first reaches nothing (target.py:109-133 over model.py:152-236, S12).
 // Output: t_hit[p] for every problem (kNotReached if none); k_compact_* turn it into the hit list.
+// Summary sink (bsx_run_target_summary): hits are counted by first-hit time in a per-workgroup LDS histogram
+// that is added to the HBM one at the end; t_hit may then be null -- nothing per problem leaves the chip.
 constexpr uint32_t kNotReached = 0xFFFFFFFFu;
 
 template <int NW, int K, int LM>
@@ -24,6 +26,12 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
     const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool simple_space = bsx::simple_space(P.sp);
+    uint32_t* hist = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);       // LDS, P.hist_bins counters
+    const uint32_t last_bin = P.hist_bins - 1;
+    if (P.hist) {
+        for (uint32_t i = threadIdx.x; i < P.hist_bins; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+    }
 
     uint32_t A[NW], B[NW], fm[NW], fv[NW], tm[NW], tc[NW];
 #pragma unroll
@@ -82,7 +90,8 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
                 const bool closed = !reached && !capped && eq_words<NW>(nxt, B);     // every state has been checked
                 const bool tele = !closed && lam1 == power;
                 if (reached | capped | closed) {
-                    P.t_hit[my_p] = reached ? t : kNotReached;
+                    if (P.t_hit) P.t_hit[my_p] = reached ? t : kNotReached;
+                    if (P.hist && reached) atomicAdd(&hist[t < last_bin ? t : last_bin], 1u);
                     n_hits += reached ? 1u : 0u;
                     limit_hits += (capped && t_cap == kStepLimit) ? 1u : 0u;
                     steps_exec += t;
@@ -101,6 +110,11 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
                 if (t == tp) { phase = PH_BRENT; lam = 0; power = 1; copy_words<NW>(B, A); }
             }
         }
+    }
+    if (P.hist) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < P.hist_bins; i += blockDim.x)
+            if (hist[i]) atomicAdd(&P.hist[i], (unsigned long long)hist[i]);
     }
     wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps_exec, lane);
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps_exec, lane);

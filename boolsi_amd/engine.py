@@ -161,6 +161,14 @@ class Engine:
         return ix
 
     # -- runs ---------------------------------------------------------------------------------
+    def attract_fgraph(self, first, count, max_t=inf, max_len=inf, cap=65536):
+        """attract through the functional graph (spaces with n <= 32 nodes, all 'any'); same result as attract."""
+        table = np.zeros(cap, _lib.ATTR_REC)
+        n_out, none, st = C.c_uint32(), C.c_uint64(), Stats()
+        self._check(self._lib.bsx_run_attract_fgraph(self._h, C.byref(self.index(first)), count, _cap(max_t), _cap(max_len),
+                                                     ptr(table), cap, C.byref(n_out), C.byref(none), C.byref(st)))
+        return AttractResult(table[:n_out.value].copy(), none.value, None, st.as_dict())
+
     def attract(self, first, count, max_t=inf, max_len=inf, per_problem=False, cap=65536):
         # the output table is reused between calls (the library fills table[0..n_out), which is copied out)
         table = getattr(self, '_attr_table', None)
@@ -186,6 +194,20 @@ class Engine:
         self._check(self._lib.bsx_run_target(self._h, C.byref(self.index(first)), count, _cap(max_t), ptr(m), ptr(c),
                                              ptr(hits), cap, C.byref(n_hits), C.byref(st)))
         return hits[:n_hits.value], st.as_dict()      # ascending offset order (ABI contract)
+
+    def target_summary(self, first, count, max_t, mask_words, code_words, hist_bins=0, cap=0):
+        """Hits counted on the device: -> (n_hits, histogram of first-hit times (last bin = that time or later),
+        the first min(n_hits, cap) hits in index order, stats).  Nothing per problem crosses PCIe."""
+        hist = np.zeros(max(hist_bins, 1), np.uint64)
+        hits = np.zeros(max(cap, 1), _lib.HIT)
+        m = np.ascontiguousarray(mask_words, np.uint64)
+        c = np.ascontiguousarray(code_words, np.uint64)
+        n_hits, n_listed = C.c_uint64(), C.c_uint64()
+        st = Stats()
+        self._check(self._lib.bsx_run_target_summary(
+            self._h, C.byref(self.index(first)), count, _cap(max_t), ptr(m), ptr(c), ptr(hist) if hist_bins else None,
+            hist_bins, ptr(hits) if cap else None, cap, C.byref(n_hits), C.byref(n_listed), C.byref(st)))
+        return n_hits.value, hist[:hist_bins], hits[:n_listed.value], st.as_dict()
 
     def simulate(self, first, count, max_t, trajectories=True, final=True, digest=True):
         W = self.net.n_words

@@ -143,11 +143,31 @@ int  bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count,
                      bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
                      uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats);
 
+/* attract through the functional graph (no reference analogue: the reference re-simulates every trajectory,
+ * mpi.py:521-538): for spaces whose n <= 32 nodes are all 'any' (no variations, no perturbations) the network
+ * is a function on 2^n states; successor array, pointer doubling and pointer jumping over 2^n-sized arrays in
+ * HBM give every problem's (key, length, trajectory_l) without stepping trajectories.  Same results as
+ * bsx_run_attract; other spaces return BSX_ERR_UNSUPPORTED. */
+int  bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint64_t count,
+                            uint64_t max_t, uint64_t max_len,
+                            bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
+                            uint64_t* n_no_attractor, bsx_stats* stats);
+
 /* target (target.py:109-133): hits in ascending offset order into hits[0..*n_hits); mask/code are W words
  * (target node set / target substate code, input.py:580-661). */
 int  bsx_run_target(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                     const uint64_t* mask_words, const uint64_t* code_words,
                     bsx_hit* hits, uint64_t cap, uint64_t* n_hits, bsx_stats* stats);
+
+/* target with an on-device summary instead of the full hit list, for sweeps whose hits cannot (and need
+ * not) all travel to the host: *n_hits = number of problems that reach the target; hist[b] = those whose
+ * first hit is at t == b for b < hist_bins - 1, hist[hist_bins - 1] = at that time or later (hist_bins may
+ * be 0, at most 2048); hits[0..*n_listed) = the FIRST min(*n_hits, cap) hits in ascending offset order --
+ * what the reference's -n option keeps (simulate.py:163-164, mpi.py:537-538); cap may be 0. */
+int  bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                            const uint64_t* mask_words, const uint64_t* code_words,
+                            uint64_t* hist, uint32_t hist_bins, bsx_hit* hits, uint64_t cap,
+                            uint64_t* n_hits, uint64_t* n_listed, bsx_stats* stats);
 
 /* simulate (simulate.py:97-131 == s(0..max_t) by plain stepping): any of the three sinks may
  * be NULL.  trajectories[(p * (max_t + 1) + t) * W + w], final_states[p * W + w], digests[p]

@@ -1,0 +1,133 @@
+"""
+Cube collapse: aligned blocks of problems enumerated by the digits their first update depends
+on, each class standing for 2^(a-r) problems.  An exact shortcut, so: identical tables, no-attractor counts
+and reference step counts as the plain enumeration (BSX_CUBES=0) and as the CPU oracle, on aligned and ragged
+ranges, tight caps, members that are cycle states themselves (mu = 0), and attractors met first by a cube pass.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from boolsi_amd import synth
+from boolsi_amd.compile import compile_problem
+from boolsi_amd.constants import Mode
+from boolsi_amd.engine import key_to_int
+from boolsi_amd.input import parse_input_text
+
+pytestmark = pytest.mark.gpu
+CORES = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+
+@pytest.fixture()
+def eng():
+    from boolsi_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+    os.environ.pop('BSX_CUBES', None)
+
+
+def rows(table):
+    return sorted((key_to_int(a['key']), int(a['length']), int(a['count']), int(a['sum_l']),
+                   int(a['sum_l2_lo']) + (int(a['sum_l2_hi']) << 64)) for a in table)
+
+
+def merged_rows(tables):
+    acc = {}
+    for t in tables:
+        for k, length, c, s1, s2 in rows(t):
+            e = acc.setdefault((k, length), [0, 0, 0])
+            e[0] += c; e[1] += s1; e[2] += s2
+    return sorted((k, length, *v) for (k, length), v in acc.items())
+
+
+def setup(eng, text, max_t=4096):
+    cfg = parse_input_text(text, max_t, Mode.ATTRACT)
+    net, space = compile_problem(cfg)
+    eng.set_problem(net, space)
+    return net, space
+
+
+def same_as_oracle(eng, net, space, first, count, max_t=4096, max_len=None):
+    from oracle.cpu_oracle import Oracle
+    got = eng.attract(first, count, max_t, np.inf if max_len is None else max_len)
+    _, table, none, steps = Oracle(net, space).attract(first, count, max_t, max_len, per_problem=False, n_threads=CORES)
+    assert rows(got.table) == rows(table)
+    assert got.n_no_attractor == none
+    assert got.stats['state_steps'] == steps
+    return got
+
+
+def test_cubes_vs_oracle_aligned_ragged_and_capped(eng):
+    net, space = setup(eng, synth.north_star_yaml())
+    base = 0x0123456789ABCDEF & ~((1 << 28) - 1)
+    same_as_oracle(eng, net, space, base, 1 << 24)                           # one cube (+ the discovery sample)
+    g = same_as_oracle(eng, net, space, base + (1 << 24), 1 << 24)
+    assert g.stats['executed_steps'] < (1 << 24) // 4                        # ... and it did collapse
+    same_as_oracle(eng, net, space, base + 12345, (1 << 24) + 777)           # ragged head and tail around cubes
+    same_as_oracle(eng, net, space, base - (1 << 20) - 3, (1 << 22) + 5)     # crosses a 2^28 boundary
+    same_as_oracle(eng, net, space, base, 1 << 22, max_t=9, max_len=3)       # tight caps: classes run past the cap
+    same_as_oracle(eng, net, space, base, 1 << 22, max_t=30)
+    same_as_oracle(eng, net, space, 0, 1 << 23)                              # the block at digit value 0
+
+
+@pytest.mark.parametrize('text,bits', [(synth.config3_yaml(), 32), (synth.network_yaml(128, 2, 129), 128),
+                                       (synth.network_yaml(48, 3, 481), 48)])
+def test_cubes_vs_oracle_other_networks(eng, text, bits):
+    net, space = setup(eng, text)
+    same_as_oracle(eng, net, space, 0, 1 << 22)
+    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << 21) + 99)
+
+
+def test_first_contact_with_an_attractor_in_a_cube_pass(eng):
+    """Fresh engine, nothing cached beyond what the discovery sample finds: whatever attractor shows up first
+    inside a cube pass must be learnt (detector from the listed class states) and the pass repeated."""
+    from oracle.cpu_oracle import Oracle
+    net, space = setup(eng, open(os.path.join(os.path.dirname(__file__), 'golden', 'cambium2.yaml')).read(), np.inf)
+    got = eng.attract(0, 1 << 30)                    # 39 attractors, some with basins of a few hundred states
+    assert len(got.table) == 39 and int(got.table['count'].sum()) == 1 << 30 and got.n_no_attractor == 0
+    os.environ['BSX_CUBES'] = '0'
+    plain = eng.attract(0, 1 << 30)
+    assert rows(got.table) == rows(plain.table) and got.stats['state_steps'] == plain.stats['state_steps']
+
+
+def test_members_that_are_cycle_states_themselves(eng):
+    """Rules x0..x2 keep their state, x5 is constant 1, the rest constant 0: eight fixed points, each the ONLY
+    mu = 0 member of its class, and (bit 5 set) not its class representative."""
+    n = 20
+    names = ['x{}'.format(i) for i in range(n)]
+    rule = {i: names[i] for i in range(3)}
+    rule[5] = '{0} or not {0}'.format(names[5])
+    lines = ['nodes:'] + ['    - ' + v for v in names] + ['', 'update rules:']
+    lines += ['    {}: {}'.format(names[i], rule.get(i, '{0} and not {0}'.format(names[i]))) for i in range(n)]
+    lines += ['', 'initial state:'] + ['    {}: any'.format(v) for v in names]
+    net, space = setup(eng, '\n'.join(lines) + '\n', np.inf)
+    got = same_as_oracle(eng, net, space, 0, 1 << n, max_t=np.inf)
+    assert sorted(int(a['count']) for a in got.table) == [1 << 17] * 8
+    assert all(int(a['sum_l']) == (1 << 17) - 1 for a in got.table)          # one member with l = 0, the others l = 1
+    same_as_oracle(eng, net, space, 1 << 16, 3 << 16, max_t=np.inf)
+
+
+def test_large_ranges_cubes_equal_plain_enumeration_and_partition(eng):
+    net, space = setup(eng, synth.north_star_yaml())
+    base = (0x0123456789ABCDEF >> 40) << 40
+    whole = eng.attract(base + 5, (1 << 34) - 9, 4096)                       # 2^34 problems in one call
+    os.environ['BSX_CUBES'] = '0'
+    parts = []
+    at, end = base + 5, base + 5 + (1 << 34) - 9
+    while at < end:
+        n = min(1 << 32, end - at)
+        parts.append(eng.attract(at, n, 4096))
+        at += n
+    os.environ.pop('BSX_CUBES')
+    assert merged_rows([whole.table]) == merged_rows([p.table for p in parts])
+    assert whole.n_no_attractor == sum(p.n_no_attractor for p in parts)
+    assert whole.stats['state_steps'] == sum(p.stats['state_steps'] for p in parts)
+    # 2^44 problems: conservation and partition invariance (what the multi-GPU split relies on)
+    n = 1 << 44
+    big = eng.attract(base, n, 4096)
+    assert int(big.table['count'].sum()) + big.n_no_attractor == n
+    quarters = [eng.attract(base + q * (n // 4), n // 4, 4096) for q in range(4)]
+    assert merged_rows([big.table]) == merged_rows([q.table for q in quarters])
+    assert big.stats['state_steps'] == sum(q.stats['state_steps'] for q in quarters)

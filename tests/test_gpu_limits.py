@@ -49,3 +49,37 @@ def test_range_past_the_end_of_the_space_is_rejected(eng):
         eng.simulate(0, n2 + 1, case['max_t'], trajectories=False)
     with pytest.raises(EngineError):
         eng.simulate(n2, 1, case['max_t'], trajectories=False)
+
+
+def _identity_yaml(n):
+    names = ['x{}'.format(i) for i in range(n)]
+    lines = ['nodes:'] + ['    - ' + v for v in names] + ['', 'update rules:']
+    lines += ['    {0}: {0}'.format(v) for v in names]
+    lines += ['', 'initial state:'] + ['    {}: any'.format(v) for v in names]
+    return '\n'.join(lines) + '\n'
+
+
+def test_sixteen_million_attractors_fit_the_device_table(eng):
+    """Identity network, n = 24: every state is its own fixed point -> 2^24 distinct attractors.  They overflow
+    the per-wave tables and the log into the HBM attractor table (VERDICT r1 #9); the result must be exact."""
+    from boolsi_amd.engine import EngineError
+    n = 24
+    cfg = parse_input_text(_identity_yaml(n), np.inf, Mode.ATTRACT)
+    net, space = compile_problem(cfg)
+    eng.set_problem(net, space)
+    total = 1 << n
+    r = eng.attract(0, total, np.inf, cap=total + 16)
+    assert len(r.table) == total and r.n_no_attractor == 0
+    assert np.array_equal(np.sort(r.table['key'][:, 0]), np.arange(total, dtype=np.uint64))
+    assert (r.table['count'] == 1).all() and (r.table['length'] == 1).all()
+    assert not r.table['sum_l'].any() and not r.table['sum_l2_lo'].any()
+    assert r.stats['state_steps'] == total                                     # mu = 0, lambda = 1 each
+    # a second, smaller run on the same handle starts from an empty table
+    r2 = eng.attract(12345, 1 << 18, np.inf, cap=1 << 19)
+    assert np.array_equal(np.sort(r2.table['key'][:, 0]), np.arange(12345, 12345 + (1 << 18), dtype=np.uint64))
+    # the caller's capacity is the limit, loudly
+    with pytest.raises(EngineError) as e:
+        eng.attract(0, 1 << 20, np.inf, cap=1 << 16)
+    assert e.value.status == -5
+    r3 = eng.attract(0, 1 << 16, np.inf, cap=1 << 17)                          # and the handle is still usable
+    assert len(r3.table) == 1 << 16

@@ -41,11 +41,14 @@ def merged_rows(tables):
     return sorted((k, length, *v) for (k, length), v in acc.items())
 
 
-def test_north_star_counting_mode_tile_equals_oracle_table(eng):
-    """2^26 consecutive north-star problems in one call = one probe tile (member masks) + one big tile in
+@pytest.mark.parametrize('cubes', ['0', '1'])
+def test_north_star_counting_mode_tile_equals_oracle_table(eng, cubes, monkeypatch):
+    """cubes = 0: 2^26 consecutive north-star problems in one call = one probe tile (member masks) + one big tile in
     counting mode, exactly what bench.py runs; table, no-attractor count and reference step count must be
-    the oracle's (which walks every trajectory: ~20 s on the box's host cores)."""
+    the oracle's (which walks every trajectory: ~20 s on the box's host cores).
+    cubes = 1: the same range through the default path, the cube collapse."""
     from oracle.cpu_oracle import Oracle
+    monkeypatch.setenv('BSX_CUBES', cubes)
     cfg = parse_input_text(synth.north_star_yaml(), 4096, Mode.ATTRACT)
     net, space = compile_problem(cfg)
     eng.set_problem(net, space)
