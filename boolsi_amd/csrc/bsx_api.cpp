@@ -30,8 +30,8 @@ hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
 size_t pool_extra_bytes(uint32_t nw);
-hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, uint32_t fixmask,
-                          uint32_t fixval, uint64_t n_states, uint32_t* succ);
+hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, const DevSpace& sp,
+                          uint64_t n_states, uint32_t* succ, uint32_t warm_steps);
 hipError_t launch_fg_double(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t cus, hipStream_t st);
 hipError_t launch_fg_mark(const uint32_t* land, uint64_t n, uint32_t* bits, uint32_t cus, hipStream_t st);
 hipError_t launch_fg_collect(uint32_t* bits, uint64_t n_words, uint32_t* cand, uint32_t cand_cap, unsigned int* cursor, uint32_t cus, hipStream_t st);
@@ -39,7 +39,8 @@ hipError_t launch_fg_cycles(const uint32_t* succ, const uint32_t* cand, uint32_t
                             unsigned int* n_cyclic, unsigned int* n_open, hipStream_t st);
 hipError_t launch_fg_pair_init(const uint32_t* succ, const void* cyc, uint32_t cyc_mask, unsigned long long* pair, uint64_t n, uint32_t cus, hipStream_t st);
 hipError_t launch_fg_pair_jump(unsigned long long* pair, uint64_t n, uint32_t d_cap, unsigned int* changed, uint32_t cus, hipStream_t st);
-hipError_t launch_fg_aggregate(const unsigned long long* pair, const void* cyc, uint32_t cyc_mask, uint64_t first, uint64_t count,
+hipError_t launch_fg_aggregate(const unsigned long long* pair, const void* cyc, uint32_t cyc_mask, const uint32_t* warm, uint32_t tp,
+                               uint64_t first, uint64_t count,
                                uint64_t cap_rel, uint64_t max_len, uint64_t max_t, const AttractParams& P, uint32_t cus, hipStream_t st);
 size_t fg_cyc_entry_bytes();
 hipError_t launch_table_drain(LogRec* tab, uint64_t slots, LogRec* out, uint64_t out_cap, unsigned long long* cursor, hipStream_t st);
@@ -1174,8 +1175,9 @@ extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint
     if (int rc = check_range(h, first, count)) return rc;
     if (int rc = check_max_t(h, max_t)) return rc;
     const uint32_t n = h->n_nodes;
-    if (n > 32 || h->sp.n_any != n || !h->sp.identity_any || h->sp.n_fv || h->sp.n_pv || h->sp.tp_origin || h->lut_mode == 2)
-        return fail(h, BSX_ERR_UNSUPPORTED, "functional-graph mode needs n <= 32 nodes, all of them 'any', no variations, no perturbations");
+    if (n > 32 || h->sp.n_any != n || !h->sp.identity_any || h->sp.n_fv || h->sp.n_pv || h->lut_mode == 2)
+        return fail(h, BSX_ERR_UNSUPPORTED, "functional-graph mode needs n <= 32 nodes, all of them 'any', and no variations");
+    const uint32_t tp = h->sp.tp_origin;                    // origin perturbations: the search starts at s(T_p)
     const double t_begin = now_ms();
     HIPCHK(h, hipSetDevice(h->device));
     *n_out = 0;
@@ -1195,11 +1197,12 @@ extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint
     const uint64_t N = 1ull << n;
     const uint32_t cus = (uint32_t)h->prop.multiProcessorCount;
     const bool capped = max_t != BSX_T_INF;
-    // doubling rounds: 2^rounds must reach every transient that can still be "found" (mu + lambda <= max_t);
-    // without a cap, every transient (mu < N)
+    const uint64_t cap_rel = capped ? max_t - tp : UINT64_MAX;     // found iff mu + lambda <= max_t - T_p (S7)
+    // doubling rounds: 2^rounds must reach every transient that can still be "found"; without a cap, every
+    // transient (mu < N)
     uint32_t rounds = 0;
-    while (rounds < n && (!capped || (1ull << rounds) <= max_t)) ++rounds;
-    const uint64_t walk_cap = capped ? std::max<uint64_t>(max_t, 1) : (1ull << 22);
+    while (rounds < n && (!capped || (1ull << rounds) <= cap_rel)) ++rounds;
+    const uint64_t walk_cap = capped ? std::max<uint64_t>(cap_rel, 1) : (1ull << 22);
     const uint32_t cand_cap = 1u << 22;
 
     DevBuf<uint32_t>& succ = h->d_fg_a;
@@ -1222,9 +1225,13 @@ extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint
     // A: successor array
     {
         const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 4, (N + kBlock - 1) / kBlock));
-        HIPCHK(h, launch_fg_succ((int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, h->net,
-                                 h->sp.fixmask[0], h->sp.fixval[0], N, succ.p));
+        HIPCHK(h, launch_fg_succ((int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, h->net, h->sp, N, succ.p, 0));
         ++launches;
+        if (tp) {
+            HIPCHK(h, h->d_fg_warm.reserve(N));
+            HIPCHK(h, launch_fg_succ((int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, h->net, h->sp, N, h->d_fg_warm.p, tp));
+            ++launches;
+        }
     }
     // B: landing points f^(2^rounds)(s)
     const uint32_t* land = succ.p;
@@ -1261,7 +1268,7 @@ extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint
     unsigned long long* pair = ((const void*)(ja.p + N) == (const void*)jb.p) ? reinterpret_cast<unsigned long long*>(ja.p) : h->d_fg_pair.p;
     HIPCHK(h, launch_fg_pair_init(succ.p, d_cyc.p, cyc_slots - 1, pair, N, cus, h->stream));
     ++launches;
-    const uint32_t d_cap = capped ? (uint32_t)std::min<uint64_t>(max_t, 0xFFFFFFFEull) : 0xFFFFFFFEu;
+    const uint32_t d_cap = capped ? (uint32_t)std::min<uint64_t>(cap_rel, 0xFFFFFFFEull) : 0xFFFFFFFEu;
     for (uint32_t r = 0; r < n + 2; ++r) {
         HIPCHK(h, hipMemsetAsync(d_small.p + 3, 0, 4, h->stream));
         HIPCHK(h, launch_fg_pair_jump(pair, N, d_cap, d_small.p + 3, cus, h->stream));
@@ -1276,7 +1283,7 @@ extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint
     P.table = h->d_table.p;
     P.table_mask = h->table_slots - 1;
     const uint64_t first_state = first->init_digits[0];
-    HIPCHK(h, launch_fg_aggregate(pair, d_cyc.p, cyc_slots - 1, first_state, count, capped ? max_t : UINT64_MAX, max_len,
+    HIPCHK(h, launch_fg_aggregate(pair, d_cyc.p, cyc_slots - 1, tp ? h->d_fg_warm.p : nullptr, tp, first_state, count, cap_rel, max_len,
                                   capped ? max_t : 0, P, cus, h->stream));
     ++launches;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -1297,7 +1304,7 @@ extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint
     if (stats) {
         stats->problems = count;
         stats->state_steps = ctr.steps_ref;
-        stats->executed_steps = N;                  // one network update per state of the space
+        stats->executed_steps = N * (1 + (uint64_t)tp);     // one network update per state of the space (+ the warm-up map)
         stats->kernel_ms = ms;
         stats->kernel_launches = launches;
         stats->total_ms = now_ms() - t_begin;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
 
     // ---- epilogue: lane caches -> wave table -> HBM log; counters
     table_merge<NW>(P, slot, lane, ccnt != 0, ck, clen, ccnt, csl, csl2);
-    if (slot.count) log_append<NW>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
+    if (slot.count) log_append<NW, true>(P, slot.key, slot.length, slot.count, slot.sum_l, slot.sum_l2);
 #ifdef BSX_DIAG
     if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_service); }
 #endif

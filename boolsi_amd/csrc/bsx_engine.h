@@ -95,7 +95,7 @@ struct bsx_engine {
     bsx::DevBuf<bsx::Counters> d_ctr;
 
     // functional-graph mode (bsx_fgraph.hip): N-sized arrays, kept between calls (grow-only)
-    bsx::DevBuf<uint32_t> d_fg_a, d_fg_b, d_fg_c;
+    bsx::DevBuf<uint32_t> d_fg_a, d_fg_b, d_fg_c, d_fg_warm;
     bsx::DevBuf<unsigned long long> d_fg_pair;
 
     // RCCL communicator of this handle's rank (bsx_comm.cpp); librccl is loaded on first use

@@ -8,7 +8,9 @@
 //      a cycle state: (key = min state of its cycle, lambda) goes into a small hash table `cyc`
 //   D  pair[s] = (p, d) with f^d(s) = p, halting at cycle states: init (s, 0) / (f(s), 1), then in-place
 //      pointer jumping  (p, d) <- (pair[p].p, d + pair[p].d)  until nothing changes: d = mu, p = entry state
-//   E  aggregate (count, sum mu, sum mu^2) per attractor over the problems [first, first + count)
+//   E  aggregate (count, sum l, sum l^2) per attractor over the problems [first, first + count)
+// Origin perturbations (a warm-up of T_p steps, model.py:76-128) only move the start of the search: one more
+// array warm[s] = s(T_p), and problem s reads the pair of warm[s]; trajectory_l = T_p + mu.
 // Every pass streams whole arrays, so this is the one mode of the engine whose bound really is HBM.  The
 // 64-bit pair is read and written whole, so the invariant f^d(s) = p survives any interleaving of phase D.
 #include "bsx_kernels_common.h"
@@ -23,9 +25,10 @@ __device__ __forceinline__ uint32_t cyc_code(uint32_t s) { return s + 1u; }
 
 struct FgParams {
     DevNet net;
-    uint32_t fixmask, fixval;
+    DevSpace sp;                // origin fixed nodes and perturbation schedule (no variations in this mode)
     uint64_t n_states;
     uint32_t* succ;
+    uint32_t warm_steps;        // 0: succ[s] = f(s); T_p > 0: succ[s] = s(T_p) from s(0) = s under the origin perturbations
 };
 
 template <int K, int LM>
@@ -33,13 +36,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_fg_succ(const FgParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
     const NetView<1, K, LM> nv = stage_network<1, K, LM>(P.net, smem, smem_free);
-    const uint32_t fm[1] = {P.fixmask}, fv[1] = {P.fixval};
-    const bool has_fixed = P.fixmask != 0;
+    const uint32_t fm[1] = {P.sp.fixmask[0]}, fv[1] = {P.sp.fixval[0]};
+    const bool has_fixed = fm[0] != 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < P.n_states; s += stride) {
-        const uint32_t cur[1] = {(uint32_t)s};
+        uint32_t cur[1] = {(uint32_t)s};
         uint32_t nxt[1];
         net_step<1, K>(nv, cur, fm, fv, nxt, has_fixed);
+        for (uint32_t t = 1; t <= P.warm_steps; ++t) {          // warm-up map (model.py:76-128), uniform trip count
+            apply_perturbations<1>(P.sp, t, 0ull, nxt);
+            if (t == P.warm_steps) break;
+            cur[0] = nxt[0];
+            net_step<1, K>(nv, cur, fm, fv, nxt, has_fixed);
+        }
         P.succ[s] = nxt[0];
     }
 }
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256) void k_fg_pair_jump(unsigned long long* pair, 
 constexpr uint32_t kFgSlots = 256;
 
 __global__ __launch_bounds__(256) void k_fg_aggregate(const unsigned long long* __restrict__ pair, const CycEntry* cyc, uint32_t cyc_mask,
+                                                      const uint32_t* __restrict__ warm, uint32_t tp,
                                                       uint64_t first, uint64_t count, uint64_t cap_rel, uint64_t max_len,
                                                       uint64_t max_t, const AttractParams P) {
     __shared__ uint32_t s_key[kFgSlots], s_len[kFgSlots];          // key + 1 (0 = empty)
@@ -165,11 +175,12 @@ __global__ __launch_bounds__(256) void k_fg_aggregate(const unsigned long long* 
         bool valid = i < count;
         uint32_t key = 0, lam = 0, mu = 0;
         if (valid) {
-            const unsigned long long a = pair[first + i];
+            const unsigned long long a = pair[warm ? (uint64_t)warm[first + i] : first + i];      // search starts at s(T_p)
             mu = (uint32_t)(a >> 32);
             const bool on = cyc_find(cyc, cyc_mask, (uint32_t)a, key, lam);
-            const bool found = on && (uint64_t)mu + lam <= cap_rel;         // S7: mu + lambda <= max_t
-            steps_ref += found ? (unsigned long long)mu + lam : max_t;     // model.py:201
+            const bool found = on && (uint64_t)mu + lam <= cap_rel;         // S7: mu + lambda <= max_t - T_p
+            steps_ref += found ? (unsigned long long)tp + mu + lam : max_t; // model.py:201
+            mu += tp;                                                       // trajectory_l = T_p + mu (attract.py:291-298)
             if (!found || (uint64_t)lam > max_len) { ++n_none; valid = false; }
         }
         uint64_t todo = __ballot(valid);
@@ -228,9 +239,9 @@ static const void* fg_succ_kernel(int lut_mode) {
     return nullptr;
 }
 
-hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, uint32_t fixmask,
-                          uint32_t fixval, uint64_t n_states, uint32_t* succ) {
-    FgParams P{net, fixmask, fixval, n_states, succ};
+hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, const DevSpace& sp,
+                          uint64_t n_states, uint32_t* succ, uint32_t warm_steps) {
+    FgParams P{net, sp, n_states, succ, warm_steps};
     const void* fn = nullptr;
     switch (k) {
         case 1: fn = fg_succ_kernel<1>(lut_mode); break;
@@ -276,10 +287,11 @@ hipError_t launch_fg_pair_jump(unsigned long long* pair, uint64_t n, uint32_t d_
     hipLaunchKernelGGL(k_fg_pair_jump, fg_grid(n, cus), dim3(256), 0, st, pair, n, d_cap, changed);
     return hipGetLastError();
 }
-hipError_t launch_fg_aggregate(const unsigned long long* pair, const void* cyc, uint32_t cyc_mask, uint64_t first, uint64_t count,
+hipError_t launch_fg_aggregate(const unsigned long long* pair, const void* cyc, uint32_t cyc_mask, const uint32_t* warm, uint32_t tp,
+                               uint64_t first, uint64_t count,
                                uint64_t cap_rel, uint64_t max_len, uint64_t max_t, const AttractParams& P, uint32_t cus, hipStream_t st) {
-    hipLaunchKernelGGL(k_fg_aggregate, fg_grid(count, cus), dim3(256), 0, st, pair, static_cast<const CycEntry*>(cyc), cyc_mask, first, count,
-                       cap_rel, max_len, max_t, P);
+    hipLaunchKernelGGL(k_fg_aggregate, fg_grid(count, cus), dim3(256), 0, st, pair, static_cast<const CycEntry*>(cyc), cyc_mask, warm, tp,
+                       first, count, cap_rel, max_len, max_t, P);
     return hipGetLastError();
 }
 size_t fg_cyc_entry_bytes() { return sizeof(CycEntry); }

@@ -414,6 +414,21 @@ __device__ __forceinline__ NetView<NW, K, LM> stage_network(const DevNet& net, u
     return nv;
 }
 
+// Fold digest of a trajectory (simulate's checksum sink, include/bsx.h): FNV-1a over the 64-bit words of
+// X = xor of all s(t), Y = xor of the s(t) at times with digest_ybit(t), and s(T).  Built from XORs of whole
+// states so that the bit-sliced kernels can keep it per row.
+__device__ __forceinline__ uint32_t digest_ybit(uint32_t t) { return (t * 0x9E3779B1u) >> 31; }
+template <int NW>
+__device__ __forceinline__ uint64_t digest_fold_words(uint64_t dg, const uint32_t (&s)[NW], uint32_t w64) {
+#pragma unroll
+    for (int w = 0; w < (NW + 1) / 2; ++w) {
+        uint64_t word = s[2 * w];
+        if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+        if ((uint32_t)w < w64) dg = (dg ^ word) * kDigestPrime;
+    }
+    return dg;
+}
+
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane) {
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
     const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
@@ -460,7 +475,7 @@ __device__ __forceinline__ uint32_t hash_state(const uint32_t (&s)[NW]);
 // slot finishes writing it in the same iteration in which its wave-mates find it busy, so spinning lanes of
 // the same wave cannot starve the writer.
 template <int NW>
-__device__ __noinline__ void table_insert(const AttractParams& P, const uint32_t (&key)[NW], uint32_t length,
+__device__ __forceinline__ void table_insert(const AttractParams& P, const uint32_t (&key)[NW], uint32_t length,
                                           uint64_t count, uint64_t sl, uint64_t sl2, uint64_t sl2_hi) {
     uint32_t hsh = hash_state<NW>(key) * 0x9E3779B1u;
 #pragma unroll
@@ -508,7 +523,9 @@ __device__ __noinline__ void table_insert(const AttractParams& P, const uint32_t
     }
 }
 
-template <int NW>
+// kTable: the caller's records may spill into the HBM table (general kernel); the lean / pool kernels write at
+// most one record per workgroup and attractor and are built without that code.
+template <int NW, bool kTable = false>
 __device__ __forceinline__ void log_append(const AttractParams& P, const uint32_t (&key)[NW], uint32_t length,
                                            uint64_t count, uint64_t sl, uint64_t sl2, uint64_t sl2_hi = 0) {
     const unsigned long long at = atomicAdd(&P.ctr->log_cursor, 1ull);
@@ -520,9 +537,11 @@ __device__ __forceinline__ void log_append(const AttractParams& P, const uint32_
         for (int w = 0; w < NW; ++w) r.key[w] = key[w];
         r.length = length; r.pad = 0; r.count = count; r.sum_l = sl; r.sum_l2_lo = sl2; r.sum_l2_hi = sl2_hi;
         P.log[at] = r;
-    } else if (P.table) {                       // log full: straight into the HBM table
-        atomicAdd(&P.ctr->table_inserts, 1ull);
-        table_insert<NW>(P, key, length, count, sl, sl2, sl2_hi);
+    } else if (kTable && P.table) {             // log full: straight into the HBM table
+        if constexpr (kTable) {
+            atomicAdd(&P.ctr->table_inserts, 1ull);
+            table_insert<NW>(P, key, length, count, sl, sl2, sl2_hi);
+        }
     } else {
         atomicOr(&P.ctr->log_overflow, 1u);
     }
@@ -556,7 +575,7 @@ __device__ __forceinline__ void table_merge(const AttractParams& P, TableSlot<NW
                 slot.length = len; slot.count = cnt; slot.sum_l = a; slot.sum_l2 = b;
             }
         } else if (lane == 0) {
-            log_append<NW>(P, k, len, cnt, a, b);    // all 64 slots taken: straight to the HBM log
+            log_append<NW, true>(P, k, len, cnt, a, b);    // all 64 slots taken: straight to the HBM log
         }
     }
 }

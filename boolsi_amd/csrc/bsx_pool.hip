@@ -159,7 +159,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 
     const uint32_t cap_rel = (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)(P.max_t - tp);
 
-    unsigned long long extra_ref = 0, n_none = 0, n_capfail = 0;
+    // member counts: 64 bits in a cube pass (a class stands for up to 2^48 problems), 32 bits otherwise (a tile
+    // has at most 2^28 problems) -- the plain build keeps its registers
+    using cnt_t = std::conditional_t<CUBE, unsigned long long, uint32_t>;
+    unsigned long long extra_ref = 0;
+    cnt_t n_none = 0, n_capfail = 0;
     uint32_t nexec = 0;
     WaveQueue q{0, 0, true};
     uint32_t head = 0, count = 0;                           // pool ring (uniform)
@@ -208,26 +212,30 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     };
 
     // m members end on the cycle state with tag word `tagw` at time mu (attract.py:291-298 for each of them)
-    auto account = [&](uint32_t tagw, unsigned long long m, uint32_t mu, uint32_t lam, bool& keep_out) {
+    auto account = [&](uint32_t tagw, cnt_t m, uint32_t mu, uint32_t lam, bool& keep_out) {
         const uint32_t tg = tagw & kTagMask, traj = tp + mu;
         const bool found = mu <= cap_rel && lam <= cap_rel - mu;
         const bool keep = found && (uint64_t)lam <= P.max_len;              // attract.py:294
         keep_out = keep;
         if (__builtin_expect(!keep, 0)) {
             n_none += m;
-            n_capfail += found ? 0ull : m;
-            extra_ref += found ? m * (traj + lam) : 0ull;                   // model.py:201
+            n_capfail += found ? (cnt_t)0 : m;
+            extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
         } else {
             // Straight into the workgroup's accumulators: a wave resolves less than one class per
             // iteration on average (64 problems end as one or two classes), so the LDS atomics do not
             // queue up, and no per-lane sums have to be carried in registers.
-            const unsigned long long wl = m * traj;                         // m < 2^49, traj < 2^13
-            const unsigned long long lo = wl * traj, hi = __umul64hi(wl, (unsigned long long)traj);
-            atomicAdd(&acc_cnt[tg - 1], m);
+            const unsigned long long wl = (unsigned long long)m * traj;     // cube: m < 2^49, traj < 2^13; else m < 2^29
+            atomicAdd(&acc_cnt[tg - 1], (unsigned long long)m);
             atomicAdd(&acc_sl[tg - 1], wl);
-            const unsigned long long old = atomicAdd(&acc_sl2[tg - 1], lo);
-            const unsigned long long up = hi + ((old + lo < old) ? 1ull : 0ull);
-            if (up) atomicAdd(&acc_sl2h[tg - 1], up);
+            if constexpr (cube) {                                           // 128-bit sum of m * traj^2
+                const unsigned long long lo = wl * traj, hi = __umul64hi(wl, (unsigned long long)traj);
+                const unsigned long long old = atomicAdd(&acc_sl2[tg - 1], lo);
+                const unsigned long long up = hi + ((old + lo < old) ? 1ull : 0ull);
+                if (up) atomicAdd(&acc_sl2h[tg - 1], up);
+            } else {
+                atomicAdd(&acc_sl2[tg - 1], wl * traj);                     // < 2^57 per add, < 2^64 per workgroup
+            }
         }
     };
 
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 const uint32_t et0 = live ? probe(A, h0, true) : 0u;
                 if (et0) {
                     bool kept;
-                    account(et0, 1ull, 0u, NW <= 2 ? hit_len : lamtab[(et0 & kTagMask) - 1], kept);
+                    account(et0, (cnt_t)1, 0u, NW <= 2 ? hit_len : lamtab[(et0 & kTagMask) - 1], kept);
                     const unsigned long long left = (((unsigned long long)mhi << 32) | mlo) - 1ull;
                     mlo = (uint32_t)left; mhi = (uint32_t)(left >> 32);
                     live = left != 0;
@@ -347,7 +355,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         const uint32_t w = cand ? (uint32_t)dd_ids[slot] : lane;
 
         // ---- resolved classes: every member has mu = t
-        const unsigned long long m = counting ? (((unsigned long long)mhi << 32) | mlo) : (unsigned long long)(__popc(mlo) + __popc(mhi));
+        cnt_t m;
+        if constexpr (cube) m = ((unsigned long long)mhi << 32) | mlo;
+        else m = counting ? mlo : (uint32_t)(__popc(mlo) + __popc(mhi));
         if (live && res != 0) {
             const uint32_t tg = res & kTagMask;
             const uint32_t lam = NW <= 2 ? hit_len : lamtab[tg - 1];
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         // ---- classes past the FAST length go back as (group base, member mask)
         if (live && res == 0 && t >= fast_steps) {
             if (counting && !cube) atomicOr(&P.ctr->straggler_overflow, 2u);    // members unknown: the host repeats the tile
-            atomicAdd(&P.ctr->n_stragglers, m);
+            atomicAdd(&P.ctr->n_stragglers, (unsigned long long)m);
             const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
             if (cube) {
                 // (state, t, member count): the host runs the detector from the state; an attractor it did not
@@ -395,9 +405,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             const bool same = cand & (w != lane) & (differ == 0u);
             if (__ballot(same)) {
                 if (same) {
-                    if (counting) {
+                    if constexpr (cube) {
                         atomicAdd((unsigned long long*)(__attribute__((address_space(3))) unsigned long long*)&dd_acc[2 * w],
                                   ((unsigned long long)mhi << 32) | mlo);
+                    } else if (counting) {
+                        atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
                     } else {
                         if (mlo) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w], mlo);
                         if (mhi) atomicOr((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&dd_acc[2 * w + 1], mhi);
@@ -409,10 +421,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 if (cand) {
                     const uint32_t glo = dd_acc[2 * lane], ghi = dd_acc[2 * lane + 1];
                     if (glo | ghi) {
-                        if (counting) {
+                        if constexpr (cube) {
                             const unsigned long long sum = (((unsigned long long)mhi << 32) | mlo) + (((unsigned long long)ghi << 32) | glo);
                             mlo = (uint32_t)sum; mhi = (uint32_t)(sum >> 32);
-                        } else { mlo |= glo; mhi |= ghi; }
+                        } else if (counting) { mlo += glo; }
+                        else { mlo |= glo; mhi |= ghi; }
                         dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
                     }
                 }
@@ -462,9 +475,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #ifdef BSX_DIAG
     if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_fresh); }
 #endif
-    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : n_capfail * P.max_t), (int)lane);
+    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), (int)lane);
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, (int)lane);
-    wave_atomic_add(&P.ctr->n_none, n_none, (int)lane);
+    wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, (int)lane);
 }
 
 template <int NW, int K>

@@ -20,15 +20,20 @@ __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
         uint32_t s[NW];
         copy_words<NW>(s, pr.s);
         uint64_t* out = P.traj ? P.traj + (P.out_offsets ? P.out_offsets[qi] : qi * (P.max_t + 1) * P.w64) : nullptr;
-        uint64_t dg = kDigestSeed;
-        for (uint64_t t = 0;; ++t) {
+        // fold digest (include/bsx.h): X = xor of all s(t), Y = xor of the s(t) at times with digest_ybit(t)
+        uint32_t dx[NW], dy[NW];
 #pragma unroll
-            for (int w = 0; w < (NW + 1) / 2; ++w) {
-                uint64_t word = s[2 * w];
-                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
-                if ((uint32_t)w < P.w64) {
-                    if (out) out[t * P.w64 + w] = word;
-                    dg = (dg ^ word) * kDigestPrime;
+        for (int w = 0; w < NW; ++w) dx[w] = dy[w] = 0;
+        for (uint64_t t = 0;; ++t) {
+            const uint32_t ym = 0u - digest_ybit((uint32_t)t);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { dx[w] ^= s[w]; dy[w] ^= s[w] & ym; }
+            if (out) {
+#pragma unroll
+                for (int w = 0; w < (NW + 1) / 2; ++w) {
+                    uint64_t word = s[2 * w];
+                    if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                    if ((uint32_t)w < P.w64) out[t * P.w64 + w] = word;
                 }
             }
             if (t == T) break;
@@ -46,7 +51,13 @@ __global__ __launch_bounds__(kBlock) void k_simulate(const SimParams P) {
                 if ((uint32_t)w < P.w64) P.final_states[qi * P.w64 + w] = word;
             }
         }
-        if (P.digests) P.digests[qi] = dg;
+        if (P.digests) {
+            uint64_t dg = kDigestSeed;
+            dg = digest_fold_words<NW>(dg, dx, P.w64);
+            dg = digest_fold_words<NW>(dg, dy, P.w64);
+            dg = digest_fold_words<NW>(dg, s, P.w64);
+            P.digests[qi] = dg;
+        }
     }
     wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps, (int)(threadIdx.x & 63));
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps, (int)(threadIdx.x & 63));

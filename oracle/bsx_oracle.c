@@ -474,16 +474,25 @@ int orc_run_simulate(const orc_network* net, const orc_space* sp, const orc_inde
             uint32_t n_pert, ppos = 0;
             orc_index ix = index_add(first, p, sp->n_any);
             orc_problem_from_index(net, sp, &ix, s, fm, fv, pert, &n_pert);
-            uint64_t d = DIGEST_SEED;
+            /* fold digest (not a reference quantity; include/bsx.h): X = xor of all s(t), Y = xor of the s(t)
+             * with ybit(t), then FNV-1a over the words of X, Y and s(max_t) */
+            uint64_t x[ORC_MAX_WORDS] = {0}, y[ORC_MAX_WORDS] = {0};
             /* simulate.py:97-131 == plain stepping s(0..max_t) */
             for (uint64_t t = 0;; ++t) {
                 if (traj) memcpy(traj + (p * (max_t + 1) + t) * W, s, W * 8);
-                for (uint32_t w = 0; w < W; ++w) d = digest_step(d, s[w]);
+                const int yb = (int)(((uint32_t)t * 0x9E3779B1u) >> 31);
+                for (uint32_t w = 0; w < W; ++w) { x[w] ^= s[w]; if (yb) y[w] ^= s[w]; }
                 if (t == max_t) break;
                 step_problem(net, fm, fv, pert, n_pert, &ppos, t + 1, s);
             }
             if (final_state) memcpy(final_state + p * W, s, W * 8);
-            if (digest) digest[p] = d;
+            if (digest) {
+                uint64_t d = DIGEST_SEED;
+                for (uint32_t w = 0; w < W; ++w) d = digest_step(d, x[w]);
+                for (uint32_t w = 0; w < W; ++w) d = digest_step(d, y[w]);
+                for (uint32_t w = 0; w < W; ++w) d = digest_step(d, s[w]);
+                digest[p] = d;
+            }
         }
         free(pert);
     }

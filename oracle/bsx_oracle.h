@@ -99,7 +99,8 @@ int orc_run_target(const orc_network* net, const orc_space* sp, const orc_index*
                    orc_target_result* per_problem, uint64_t* state_steps, int n_threads);
 
 /* simulate: states s(0..max_t) of each problem -> traj[(p*(max_t+1) + t)*W + w] (may be NULL),
- * final[p*W + w], digest[p] (see orc_digest_step). */
+ * final[p*W + w], digest[p] = fold digest of s(0..max_t): FNV-1a over the words of X = xor of all s(t),
+ * Y = xor of the s(t) with ((uint32_t)t * 0x9E3779B1) >> 31 set, and s(max_t). */
 int orc_run_simulate(const orc_network* net, const orc_space* sp, const orc_index* first,
                      uint64_t count, uint64_t max_t, uint64_t* traj, uint64_t* final_state,
                      uint64_t* digest, uint64_t* state_steps, int n_threads);

@@ -196,9 +196,17 @@ def target_case(name, text, indices, max_t=inf):
 
 
 def digest_of(states, n_words):
-    d = DIGEST_SEED
-    for s in states:
+    """Fold digest of a trajectory (the engine's checksum sink for runs too long to store, include/bsx.h; not a
+    reference quantity): X = xor of all state codes, Y = xor of those at times t with ybit(t), then FNV-1a over
+    the 64-bit words of X, Y and the final state."""
+    x = y = 0
+    for t, s in enumerate(states):
         c = code_of(s)
+        x ^= c
+        if ((t * 0x9E3779B1) & 0xFFFFFFFF) >> 31:
+            y ^= c
+    d = DIGEST_SEED
+    for c in (x, y, code_of(states[-1])):
         for w in range(n_words):
             d = ((d ^ ((c >> (64 * w)) & M64)) * 0x100000001B3) & M64
     return d
