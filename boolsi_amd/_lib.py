@@ -13,7 +13,7 @@ import numpy as np
 MAX_WORDS = 4
 T_INF = 2 ** 64 - 1
 
-LIB_NAME = 'libbsx_hip.so'
+LIB_NAME = os.environ.get('BSX_LIB', 'libbsx_hip.so')      # (BSX_LIB=libbsx_hip_diag.so: diagnostic build, tools only)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 EXPORTS = (

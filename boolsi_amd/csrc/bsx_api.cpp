@@ -568,6 +568,9 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
                      kind == kPassPool ? "pool" : fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
                      (unsigned long long)run.ctr.n_stragglers, run.ms, (unsigned long long)run.ctr.wave_iters,
                      (unsigned long long)run.ctr.service_rounds);
+    if (std::getenv("BSX_DEBUG") && run.ctr.wave_iters)
+        std::fprintf(stderr, "[bsx]   diag: kept after fresh stages %llu, lanes into pool stages %llu, kept after pool stages %llu, merged away %llu\n",
+                     (unsigned long long)run.ctr.diag[0], (unsigned long long)run.ctr.diag[1], (unsigned long long)run.ctr.diag[2], (unsigned long long)run.ctr.diag[3]);
     if (!merged) return BSX_OK;                 // results discarded (discovery): a full log does not matter
     if (run.ctr.table_inserts) h->table_dirty = true;
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
@@ -1470,7 +1473,7 @@ static int run_sim_common(bsx_handle h, const bsx_index* first, uint64_t count, 
 
 // Final states of a fixed-length run through the bit-sliced kernel (no variations, no wide rules).
 static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
-                          uint64_t* final_states, bsx_stats* stats) {
+                          uint64_t* final_states, uint64_t* digests, bsx_stats* stats) {
     const double t_begin = now_ms();
     HIPCHK(h, hipSetDevice(h->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -1490,10 +1493,11 @@ static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, 
         desc[(size_t)i * 8 + 7] = (uint32_t)(tt >> 32);
     }
     DevBuf<uint32_t> d_desc, d_sched;
-    DevBuf<uint64_t> d_final;
+    DevBuf<uint64_t> d_final, d_dig;
     HIPCHK(h, d_desc.upload(desc));
     HIPCHK(h, d_sched.upload(h->h_sched));
-    HIPCHK(h, d_final.alloc(count * W));
+    if (final_states) HIPCHK(h, d_final.alloc(count * W));
+    if (digests) HIPCHK(h, d_dig.alloc(count));
 
     SlicedParams P{};
     P.sp = h->sp;
@@ -1506,7 +1510,8 @@ static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, 
     P.sched = d_sched.p;
     P.count = count;
     P.max_t = max_t;
-    P.final_states = d_final.p;
+    P.final_states = final_states ? d_final.p : nullptr;
+    P.digests = digests ? d_dig.p : nullptr;
     P.ctr = h->d_ctr.p;
 
     // K <= 3 and n <= 128: second-generation kernel (8-byte rows, constants in registers); BSX_SLICED=1 keeps the first
@@ -1526,7 +1531,8 @@ static int run_sim_sliced(bsx_handle h, const bsx_index* first, uint64_t count, 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    HIPCHK(h, hipMemcpy(final_states, d_final.p, count * W * 8, hipMemcpyDeviceToHost));
+    if (final_states) HIPCHK(h, hipMemcpy(final_states, d_final.p, count * W * 8, hipMemcpyDeviceToHost));
+    if (digests) HIPCHK(h, hipMemcpy(digests, d_dig.p, count * 8, hipMemcpyDeviceToHost));
     if (stats) {
         stats->problems = count;
         stats->state_steps = ctr.steps_ref;
@@ -1548,10 +1554,12 @@ extern "C" int bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t c
     // Long fixed-length runs that only want final states go through the bit-sliced kernel
     // (BSX_SLICED=0 forces the per-lane kernel, for A/B runs and tests).
     const char* sl_env = std::getenv("BSX_SLICED");
-    const bool sliced_ok = !(sl_env && sl_env[0] == '0') && final_states && !trajectories && !digests &&
+    // (digests: the second-generation kernel only, K <= 3 and n <= 128, which keeps them per row in registers)
+    const bool gen2_shape = h->net.k_mux <= 3 && ((h->n_nodes + 15) & ~15u) <= 128 && !(sl_env && sl_env[0] == '1');
+    const bool sliced_ok = !(sl_env && sl_env[0] == '0') && (final_states || digests) && !trajectories && (!digests || gen2_shape) &&
                            !h->sp.n_fv && !h->sp.n_pv && !h->net.n_wide && max_t >= 64 && max_t < kStepLimit &&
                            count >= 2048 && (size_t)((h->n_nodes + 15) & ~15u) * 136 * 4 <= 160 * 1024;
-    if (sliced_ok && count) return run_sim_sliced(h, first, count, max_t, final_states, stats);
+    if (sliced_ok && count) return run_sim_sliced(h, first, count, max_t, final_states, digests, stats);
     const uint64_t words = trajectories ? count * (max_t + 1) * h->w64 : 0;
     return run_sim_common(h, first, count, max_t, nullptr, nullptr, nullptr, words, trajectories, final_states,
                           digests, stats);

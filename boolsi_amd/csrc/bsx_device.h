@@ -93,6 +93,8 @@ struct Counters {               // zeroed before every launch
     unsigned int pad3;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic
+    unsigned long long diag[4];         // diagnostic (BSX_DIAG builds): pool kernel: classes kept after fresh stages,
+                                        // lanes entering pool stages, classes kept after pool stages, lanes merged away
 };
 
 // Cache of known cycle states (DESIGN.md "cycle-state cache").  A trajectory enters its attractor at
@@ -217,7 +219,8 @@ struct SlicedParams {
     const uint32_t* sched;      // [n_sched][3] (t, node, value) sorted by t
     uint64_t count;
     uint64_t max_t;
-    uint64_t* final_states;     // [count][w64]
+    uint64_t* final_states;     // nullable: [count][w64]
+    uint64_t* digests;          // nullable: [count] fold digests (second-generation kernel only)
     Counters* ctr;
 };
 

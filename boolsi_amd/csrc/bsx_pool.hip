@@ -44,7 +44,7 @@ constexpr int kPoolBlock = 768;
 constexpr int kPoolWaves = kPoolBlock / 64;
 constexpr uint32_t kPoolCap = 112;              // classes per wave (ring buffer; > 64 + what a fresh stage leaves)
 constexpr uint32_t kPoolGroup = 64;             // problems loaded together = lanes
-constexpr uint32_t kPoolSlots = 128;            // merge slots per wave (one-byte lane ids)
+constexpr uint32_t kPoolSlots = 256;            // merge slots per wave (one-byte lane ids); 128 lost a third of the pool-stage merges to slot collisions
 
 constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // state, group base, members lo/hi, time
 constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     WaveQueue q{0, 0, true};
     uint32_t head = 0, count = 0;                           // pool ring (uniform)
 #ifdef BSX_DIAG
-    unsigned long long dbg_iters = 0, dbg_fresh = 0;
+    unsigned long long dbg_iters = 0, dbg_fresh = 0, dbg_fresh_keep = 0, dbg_pool_in = 0, dbg_pool_keep = 0, dbg_merged = 0;
+    bool dbg_is_fresh = false;
 #endif
 
     // is `s` a cached cycle state?  -> the entry's tag word (0 = no); `hfull` = the state's hash
@@ -270,6 +271,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             head += n;
             head -= head >= kPoolCap ? kPoolCap : 0u;
             count -= n;
+#ifdef BSX_DIAG
+            dbg_is_fresh = false;
+            dbg_pool_in += n;
+#endif
         } else {
             // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
             if (q.next == q.end) {
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             }
 #ifdef BSX_DIAG
             ++dbg_fresh;
+            dbg_is_fresh = true;
 #endif
         }
 
@@ -403,6 +409,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
             for (int i = 0; i < NW; ++i) differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)A[i]) ^ A[i];
             const bool same = cand & (w != lane) & (differ == 0u);
+#ifdef BSX_DIAG
+            dbg_merged += __popcll(__ballot(same));
+#endif
             if (__ballot(same)) {
                 if (same) {
                     if constexpr (cube) {
@@ -434,6 +443,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 
         // ---- survivors go (back) to the pool
         const uint64_t keepers = __ballot(cand);
+#ifdef BSX_DIAG
+        if (dbg_is_fresh) dbg_fresh_keep += __popcll(keepers); else dbg_pool_keep += __popcll(keepers);
+#endif
         if (cand) {
             const uint32_t rank = __popcll(keepers & ((1ull << lane) - 1ull));
             uint32_t tail = head + count;                   // uniform; head < cap, count <= cap
@@ -473,7 +485,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         extra_ref += sl + cn * lamtab[a];                                       // + lambda each (model.py:201)
     }
 #ifdef BSX_DIAG
-    if (lane == 0) { atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_fresh); }
+    if (lane == 0) {
+        atomicAdd(&P.ctr->wave_iters, dbg_iters); atomicAdd(&P.ctr->service_rounds, dbg_fresh);
+        atomicAdd(&P.ctr->diag[0], dbg_fresh_keep); atomicAdd(&P.ctr->diag[1], dbg_pool_in);
+        atomicAdd(&P.ctr->diag[2], dbg_pool_keep); atomicAdd(&P.ctr->diag[3], dbg_merged);
+    }
 #endif
     wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), (int)lane);
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, (int)lane);

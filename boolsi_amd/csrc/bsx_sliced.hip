@@ -149,28 +149,47 @@ constexpr uint32_t kS64RowBytes = 1024;
 
 __device__ __forceinline__ uint32_t s64_skew(uint32_t k) { return k + (k >> 6); }   // scratch index, conflict-free column reads
 
-template <int K, uint32_t RD, uint32_t WR>
+// v_bfi_b32 with the third operand in an SGPR: the truth-table leaves are wave-uniform all-ones / all-zeros
+// words, and a VOP3 instruction may read one scalar register -- so half of them need no VGPR.
+__device__ __forceinline__ uint32_t bfi_s(uint32_t sel, uint32_t a, uint32_t b_uniform) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(sel), "v"(a), "s"(b_uniform));
+    return r;
+}
+
+// One step for the rows of a wave.  DIGEST: the state being read, s(t - 1), is folded into the row's digest
+// accumulators first (X always, Y when `ymask` is all ones) -- the rows in LDS are final, perturbation
+// overrides included, which the values a wave has just computed are not.
+template <int K, uint32_t RD, uint32_t WR, bool DIGEST>
 __device__ __forceinline__ void s64_step(const uint32_t (&addr)[kS64RowsPerWave][K],
-                                         const uint32_t (&leaf)[kS64RowsPerWave][1 << K], uint32_t out_addr,
-                                         uint32_t rpw) {
+                                         const uint32_t (&leaf_v)[kS64RowsPerWave][1 << (K - 1)],
+                                         const uint32_t (&leaf_s)[kS64RowsPerWave][1 << (K - 1)], uint32_t out_addr,
+                                         uint32_t rpw, bsx_u32x2 (&acc_x)[kS64RowsPerWave], bsx_u32x2 (&acc_y)[kS64RowsPerWave],
+                                         uint32_t ymask) {
     typedef const bsx_u32x2 __attribute__((address_space(3))) lds_rd;
     typedef bsx_u32x2 __attribute__((address_space(3))) lds_wr;
 #pragma unroll
     for (int r0 = 0; r0 < kS64RowsPerWave; r0 += 2) {
         if ((uint32_t)r0 >= rpw) break;                 // uniform
-        bsx_u32x2 g[2][K];
+        bsx_u32x2 g[2][K], own[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int j = 0; j < K; ++j) g[u][j] = *reinterpret_cast<lds_rd*>(addr[r0 + u][j] + RD);
+            if constexpr (DIGEST) own[u] = *reinterpret_cast<lds_rd*>(out_addr + (uint32_t)(r0 + u) * kS64RowBytes + RD);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = r0 + u;
+            if constexpr (DIGEST) {
+                acc_x[r].x ^= own[u].x; acc_x[r].y ^= own[u].y;
+                acc_y[r].x ^= own[u].x & ymask; acc_y[r].y ^= own[u].y & ymask;
+            }
             uint32_t x[1 << (K - 1)], y[1 << (K - 1)];
 #pragma unroll
             for (int i = 0; i < (1 << (K - 1)); ++i) {
-                x[i] = bfi(g[u][0].x, leaf[r][2 * i + 1], leaf[r][2 * i]);
-                y[i] = bfi(g[u][0].y, leaf[r][2 * i + 1], leaf[r][2 * i]);
+                x[i] = bfi_s(g[u][0].x, leaf_v[r][i], leaf_s[r][i]);
+                y[i] = bfi_s(g[u][0].y, leaf_v[r][i], leaf_s[r][i]);
             }
 #pragma unroll
             for (int j = 1; j < K; ++j)
@@ -186,7 +205,7 @@ __device__ __forceinline__ void s64_step(const uint32_t (&addr)[kS64RowsPerWave]
     }
 }
 
-template <int NW, int K>
+template <int NW, int K, bool DIGEST>
 __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const SlicedParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     typedef uint32_t __attribute__((address_space(3))) lds_u32;
@@ -198,8 +217,8 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
     const uint32_t rpw = rows / kS64Waves;
     const uint32_t scratch = rows * kS64RowBytes;           // byte address of the transposition scratch
 
-    // ---- per-wave constants
-    uint32_t addr[kS64RowsPerWave][K], leaf[kS64RowsPerWave][1 << K];
+    // ---- per-wave constants: leaf 2i+1 of a row in a VGPR, leaf 2i in an SGPR
+    uint32_t addr[kS64RowsPerWave][K], leaf_v[kS64RowsPerWave][1 << (K - 1)], leaf_s[kS64RowsPerWave][1 << (K - 1)];
 #pragma unroll
     for (int r = 0; r < kS64RowsPerWave; ++r) {
         const uint32_t row = wave * rpw + (uint32_t)r;
@@ -207,11 +226,27 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
         const uint32_t* d = P.desc + (size_t)(live ? row : 0) * 8;
 #pragma unroll
         for (int j = 0; j < K; ++j) addr[r][j] = d[j] * kS64RowBytes + lane * 8u;
-        const uint32_t tt = live ? d[6] : 0u;               // 2^K <= 8 table bits
+        const uint32_t tt = __builtin_amdgcn_readfirstlane(live ? d[6] : 0u);     // 2^K <= 8 table bits
 #pragma unroll
-        for (int i = 0; i < (1 << K); ++i) leaf[r][i] = 0u - ((tt >> i) & 1u);
+        for (int i = 0; i < (1 << (K - 1)); ++i) {
+            leaf_v[r][i] = 0u - ((tt >> (2 * i + 1)) & 1u);
+            leaf_s[r][i] = 0u - ((tt >> (2 * i)) & 1u);
+        }
     }
     const uint32_t out_addr = wave * rpw * kS64RowBytes + lane * 8u;
+
+    // bits `bit` of the rows at byte offset `src` (+ node * row bytes) -> the NW state words of one trajectory
+    auto gather = [&](uint32_t src, uint32_t bit, uint32_t (&s)[NW]) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            uint32_t word = 0;
+            for (uint32_t b = 0; b < 32; ++b) {
+                const uint32_t node = (uint32_t)w * 32 + b;
+                if (node < n) word |= ((*reinterpret_cast<lds_u32*>(node * kS64RowBytes + src) >> bit) & 1u) << b;
+            }
+            s[w] = word;
+        }
+    };
 
     const uint64_t n_groups = (P.count + kS64Group - 1) / kS64Group;
     for (uint64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
@@ -243,13 +278,18 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
         }
         __syncthreads();
 
+        bsx_u32x2 acc_x[kS64RowsPerWave], acc_y[kS64RowsPerWave];
+#pragma unroll
+        for (int r = 0; r < kS64RowsPerWave; ++r) { acc_x[r].x = acc_x[r].y = 0; acc_y[r].x = acc_y[r].y = 0; }
+
         // ---- T synchronous updates, buffer parity = (t - 1) & 1
         uint32_t sched_at = 0;
         uint64_t next_t = P.n_sched ? (uint64_t)P.sched[0] : ~0ull;
         for (uint64_t t = 1; t <= P.max_t; ++t) {
             const bool odd = (t & 1ull) != 0;               // odd steps read buffer 0 and write buffer 1
-            if (odd) s64_step<K, 0u, 512u>(addr, leaf, out_addr, rpw);
-            else s64_step<K, 512u, 0u>(addr, leaf, out_addr, rpw);
+            const uint32_t ymask = DIGEST ? 0u - digest_ybit((uint32_t)(t - 1)) : 0u;     // the step folds s(t - 1)
+            if (odd) s64_step<K, 0u, 512u, DIGEST>(addr, leaf_v, leaf_s, out_addr, rpw, acc_x, acc_y, ymask);
+            else s64_step<K, 512u, 0u, DIGEST>(addr, leaf_v, leaf_s, out_addr, rpw, acc_x, acc_y, ymask);
             // perturbation override at time t (model.py:68-71): whole rows of the buffer just written.
             // Every wave walks the (uniform) schedule and the wave that owns the row overwrites what it
             // has just stored, so the step's one barrier covers the override too.
@@ -270,25 +310,51 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
         }
         const uint32_t cur = (P.max_t & 1ull) ? 512u : 0u;      // buffer holding s(max_t)
 
-        // ---- final states: thread handles trajectories tid, tid + 1024, ...
-        for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x) {
-            if (base + k >= P.count) break;
-            const uint32_t src = (k >> 6) * 8u + ((k >> 5) & 1u) * 4u + cur, bit = k & 31u;
-            uint32_t s[NW];
+        // ---- digests: fold s(max_t), then X and Y rows go through the idle buffer, one after the other
+        uint64_t dg[kS64Group / (64 * kS64Waves)];
+        if constexpr (DIGEST) {
+            typedef bsx_u32x2 __attribute__((address_space(3))) lds_v2;
+            const uint32_t ymask = 0u - digest_ybit((uint32_t)P.max_t);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                uint32_t word = 0;
-                for (uint32_t b = 0; b < 32; ++b) {
-                    const uint32_t node = (uint32_t)w * 32 + b;
-                    if (node < n) word |= ((*reinterpret_cast<lds_u32*>(node * kS64RowBytes + src) >> bit) & 1u) << b;
-                }
-                s[w] = word;
+            for (int r = 0; r < kS64RowsPerWave; ++r) {
+                if ((uint32_t)r >= rpw) break;
+                const bsx_u32x2 v = *reinterpret_cast<lds_v2*>(out_addr + (uint32_t)r * kS64RowBytes + cur);
+                acc_x[r].x ^= v.x; acc_x[r].y ^= v.y;
+                acc_y[r].x ^= v.x & ymask; acc_y[r].y ^= v.y & ymask;
             }
+            const uint32_t idle = cur ^ 512u;
 #pragma unroll
-            for (int w = 0; w < (NW + 1) / 2; ++w) {
-                uint64_t word = s[2 * w];
-                if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
-                if ((uint32_t)w < P.w64) P.final_states[(base + k) * P.w64 + w] = word;
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int r = 0; r < kS64RowsPerWave; ++r) {
+                    if ((uint32_t)r >= rpw) break;
+                    *reinterpret_cast<lds_v2*>(out_addr + (uint32_t)r * kS64RowBytes + idle) = pass ? acc_y[r] : acc_x[r];
+                }
+                __syncthreads();
+                uint32_t q = 0;
+                for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x, ++q) {
+                    uint32_t s[NW];
+                    gather((k >> 6) * 8u + ((k >> 5) & 1u) * 4u + idle, k & 31u, s);
+                    dg[q] = digest_fold_words<NW>(pass ? dg[q] : kDigestSeed, s, P.w64);
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- final states: thread handles trajectories tid, tid + 1024, ...
+        uint32_t q = 0;
+        for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x, ++q) {
+            if (base + k >= P.count) break;
+            uint32_t s[NW];
+            gather((k >> 6) * 8u + ((k >> 5) & 1u) * 4u + cur, k & 31u, s);
+            if constexpr (DIGEST) P.digests[base + k] = digest_fold_words<NW>(dg[q], s, P.w64);
+            if (P.final_states) {
+#pragma unroll
+                for (int w = 0; w < (NW + 1) / 2; ++w) {
+                    uint64_t word = s[2 * w];
+                    if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
+                    if ((uint32_t)w < P.w64) P.final_states[(base + k) * P.w64 + w] = word;
+                }
             }
         }
         __syncthreads();
@@ -309,10 +375,11 @@ static hipError_t launch_sliced_nk(int, dim3 grid, size_t shmem, hipStream_t st,
 
 template <int NW, int K>
 static hipError_t launch_sliced64_nk(dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_simulate_sliced64<NW, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    const void* fn = P.digests ? (const void*)k_simulate_sliced64<NW, K, true> : (const void*)k_simulate_sliced64<NW, K, false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_simulate_sliced64<NW, K>), grid, dim3(64 * kS64Waves), shmem, st, P);
-    return hipGetLastError();
+    void* args[] = {const_cast<SlicedParams*>(&P)};
+    return hipLaunchKernel(fn, grid, dim3(64 * kS64Waves), args, shmem, st);
 }
 
 hipError_t launch_simulate_sliced(int nw, int k, dim3 grid, size_t shmem, hipStream_t st, const SlicedParams& P) {

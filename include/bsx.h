@@ -170,8 +170,11 @@ int  bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint64_t count
                             uint64_t* n_hits, uint64_t* n_listed, bsx_stats* stats);
 
 /* simulate (simulate.py:97-131 == s(0..max_t) by plain stepping): any of the three sinks may
- * be NULL.  trajectories[(p * (max_t + 1) + t) * W + w], final_states[p * W + w], digests[p]
- * (FNV-1a over the words of s(0..max_t)). */
+ * be NULL.  trajectories[(p * (max_t + 1) + t) * W + w], final_states[p * W + w], digests[p].
+ * The digest is a checksum of the whole trajectory for runs too long to store (no reference counterpart):
+ * FNV-1a (seed 0xCBF29CE484222325, prime 0x100000001B3) over the W words of X, then of Y, then of s(max_t),
+ * where X = xor of s(0..max_t) and Y = xor of the s(t) with ((uint32_t)t * 0x9E3779B1) >> 31 == 1.  XORs of
+ * whole states, so the bit-sliced kernels keep it per node row. */
 int  bsx_run_simulate(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                       uint64_t* trajectories, uint64_t* final_states, uint64_t* digests,
                       bsx_stats* stats);

@@ -479,3 +479,15 @@ def test_sliced_simulate_matches_oracle_and_per_lane_kernel(eng, name, text, max
     finally:
         os.environ.pop('BSX_SLICED')
     assert np.array_equal(final, final3)
+    # digests: per-lane kernel and (where the shape allows: K <= 3, n <= 128) the bit-sliced kernel against the oracle
+    _, ofinal, odigest, _ = orc.simulate(first, count, max_t, want_traj=False, n_threads=8)
+    _, dfinal, ddigest, _ = eng.simulate(first, count, max_t, trajectories=False, digest=True)
+    assert np.array_equal(dfinal, ofinal) and np.array_equal(ddigest, odigest)
+    _, _, ddigest2, _ = eng.simulate(first, count, max_t, trajectories=False, final=False, digest=True)   # digest sink alone
+    assert np.array_equal(ddigest2, odigest)
+    os.environ['BSX_SLICED'] = '0'
+    try:
+        _, _, ddigest3, _ = eng.simulate(first, count, max_t, trajectories=False, digest=True)
+    finally:
+        os.environ.pop('BSX_SLICED')
+    assert np.array_equal(ddigest3, odigest)

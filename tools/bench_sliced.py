@@ -17,3 +17,7 @@ for name, text in (('pert', synth.config5_yaml(max_t=10000, n_any=26)), ('nopert
             _, fin, _, st = eng.simulate(0, count, 10000, trajectories=False, digest=False)
             _, fin, _, st = eng.simulate(0, count, 10000, trajectories=False, digest=False)
             print(name, 'gen', gen, count, 'kernel_ms %.2f' % st['kernel_ms'])
+            if gen == '2':
+                _, fin, dig, st = eng.simulate(0, count, 10000, trajectories=False, digest=True)
+                _, fin, dig, st = eng.simulate(0, count, 10000, trajectories=False, digest=True)
+                print(name, 'gen', gen, count, 'with digests: kernel_ms %.2f' % st['kernel_ms'])
