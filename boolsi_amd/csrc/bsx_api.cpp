@@ -30,6 +30,7 @@ hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
 size_t pool_extra_bytes(uint32_t nw);
+hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
 hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, const DevSpace& sp,
                           uint64_t n_states, uint32_t* succ, uint32_t warm_steps);
 hipError_t launch_fg_double(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t cus, hipStream_t st);
@@ -625,8 +626,9 @@ void fold_table(MergedTable& into, const MergedTable& from) {
 struct Cube {
     uint64_t d_lo;              // first digit value (multiple of 2^a)
     uint32_t a;                 // log2 of the problems in the block
-    std::vector<uint32_t> rel;  // relevant digits, ascending
-    DevSpace sp;                // enumeration of the relevant digits' assignments
+    std::vector<uint32_t> rel;  // relevant digits: ascending from build_cube, then in class-index bit order
+    uint32_t base[kMaxW32];     // the block's fixed bits, free bits zero
+    DevSpace sp;                // enumeration of the relevant digits' assignments (plan_cube)
     uint32_t umask[kMaxW32];    // node bits of the irrelevant free digits
     uint32_t free_mask[kMaxW32];
     bool ok = false;            // false: more deposit runs than the kernels take
@@ -635,7 +637,7 @@ struct Cube {
 void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c) {
     const uint32_t n = h->n_nodes, nw = h->net.nw;
     c.d_lo = d_lo; c.a = a; c.rel.clear(); c.ok = false;
-    uint32_t base[kMaxW32];
+    uint32_t base[kMaxW32];     // origin bits + the block's fixed digits
     for (int w = 0; w < kMaxW32; ++w) { base[w] = h->sp.origin[w]; c.umask[w] = 0; c.free_mask[w] = 0; }
     std::vector<char> is_free(n, 0), relevant(n, 0);
     for (uint32_t j = 0; j < h->sp.n_any; ++j) {
@@ -668,33 +670,57 @@ void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c) {
             } while (x);
         }
     }
-    std::vector<uint32_t> rel_nodes;
     for (uint32_t j = 0; j < a; ++j) {
         const uint32_t node = h->h_any[j];
-        if (relevant[node]) { c.rel.push_back(j); rel_nodes.push_back(node); }
+        if (relevant[node]) c.rel.push_back(j);
         else c.umask[node >> 5] |= 1u << (node & 31);
     }
-    // enumeration space of the cube: class index bit q -> node rel_nodes[q], everything else fixed
+    for (uint32_t w = 0; w < (uint32_t)kMaxW32; ++w) c.base[w] = w < nw ? base[w] : 0u;
+    c.ok = c.rel.size() <= kMaxDepositRuns;
+}
+
+// Enumeration space of the cube: class-index bit q -> the node of c.rel[q] (one deposit run per relevant
+// digit, in the order c.rel lists them), everything else fixed.
+void plan_cube(const bsx_engine* h, Cube& c) {
     DevSpace sp = h->sp;
-    for (uint32_t w = 0; w < (uint32_t)kMaxW32; ++w) sp.origin[w] = w < nw ? base[w] : 0u;
-    sp.n_any = (uint32_t)rel_nodes.size();
+    for (uint32_t w = 0; w < (uint32_t)kMaxW32; ++w) sp.origin[w] = c.base[w];
+    sp.n_any = (uint32_t)c.rel.size();
     sp.identity_any = 0;
-    sp.n_runs = 0;
     for (int w = 0; w < 4; ++w) sp.first_digits[w] = 0;
     sp.first_variant = 0;
-    std::vector<uint32_t> plan;
-    for (uint32_t q = 0; q < rel_nodes.size();) {
-        uint32_t len = 1;
-        while (q + len < rel_nodes.size() && rel_nodes[q + len] == rel_nodes[q] + len && ((rel_nodes[q] + len) >> 5) == (rel_nodes[q] >> 5)) ++len;
-        plan.push_back(q | (rel_nodes[q] >> 5) << 8 | (rel_nodes[q] & 31u) << 16);
-        plan.push_back(len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u);
-        q += len;
+    sp.n_runs = (uint32_t)c.rel.size();
+    for (uint32_t q = 0; q < c.rel.size(); ++q) {
+        const uint32_t node = h->h_any[c.rel[q]];
+        sp.deposit[2 * q] = q | (node >> 5) << 8 | (node & 31u) << 16;
+        sp.deposit[2 * q + 1] = 1u;
     }
-    if (plan.size() > 2 * kMaxDepositRuns) return;
-    sp.n_runs = (uint32_t)(plan.size() / 2);
-    std::copy(plan.begin(), plan.end(), sp.deposit);
     c.sp = sp;
-    c.ok = true;
+}
+
+// Relevant digits whose influence dies out first become the lowest class-index bits (k_digit_lifetimes):
+// the classes that merge after a step or two then sit in the same batch.  A heuristic for speed only.
+int order_cube_digits(bsx_handle h, Cube& c) {
+    const uint32_t r = (uint32_t)c.rel.size();
+    if (r < 2 || r > 64 || (std::getenv("BSX_CUBE_ORDER") && std::getenv("BSX_CUBE_ORDER")[0] == '0')) return BSX_OK;
+    LifetimeParams L{};
+    L.net = h->net;
+    for (int w = 0; w < kMaxW32; ++w) { L.fixmask[w] = h->sp.fixmask[w]; L.fixval[w] = h->sp.fixval[w]; L.base[w] = c.base[w]; L.free_mask[w] = c.free_mask[w]; }
+    L.n_digits = r;
+    for (uint32_t q = 0; q < r; ++q) L.node[q] = h->h_any[c.rel[q]];
+    HIPCHK(h, h->d_life.reserve(64));
+    HIPCHK(h, hipMemsetAsync(h->d_life.p, 0, 64 * sizeof(uint32_t), h->stream));
+    L.out = h->d_life.p;
+    HIPCHK(h, launch_digit_lifetimes((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, h->shmem, h->stream, L));
+    uint32_t life[64];
+    HIPCHK(h, hipMemcpyAsync(life, h->d_life.p, sizeof(life), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<uint32_t> idx(r);
+    for (uint32_t q = 0; q < r; ++q) idx[q] = q;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return life[x] < life[y]; });
+    std::vector<uint32_t> rel(r);
+    for (uint32_t q = 0; q < r; ++q) rel[q] = c.rel[idx[q]];
+    c.rel = rel;
+    return BSX_OK;
 }
 
 // Entries of the HBM attractor table -> `merged`; the table is left empty for the next call.
@@ -1051,7 +1077,11 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 build_cube(h, (uint64_t)at, a_bits, c);
                 bool collapsed = false;
                 // worth it when the block shrinks at least fourfold (otherwise the tiles do as well and keep member masks)
-                if (c.ok && c.rel.size() + 2 <= a_bits) { if (int rc = run_cube(c, collapsed)) return rc; }
+                if (c.ok && c.rel.size() + 2 <= a_bits) {
+                    if (int rc = order_cube_digits(h, c)) return rc;
+                    plan_cube(h, c);
+                    if (int rc = run_cube(c, collapsed)) return rc;
+                }
                 const uint64_t block_end = (uint64_t)(at - lo) + (1ull << a_bits);      // (a_bits <= 48: fits)
                 if (collapsed) done = block_end;
                 else if (int rc = run_tiles(block_end)) return rc;

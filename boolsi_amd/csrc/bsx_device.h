@@ -13,7 +13,7 @@ constexpr int kTableSlots = 64;             // per-wave attractor table: one slo
 constexpr uint32_t kStepLimit = 1u << 30;   // internal per-trajectory step limit (u32 counters)
 constexpr uint64_t kDigestSeed = 0xCBF29CE484222325ull;
 constexpr uint64_t kDigestPrime = 0x100000001B3ull;
-constexpr uint32_t kMaxDepositRuns = 32;
+constexpr uint32_t kMaxDepositRuns = 64;
 
 // Network tables in HBM (staged into LDS by each workgroup where they fit).
 struct DevNet {
@@ -170,6 +170,24 @@ struct AttractParams {
     uint32_t cube_free[kMaxW32];
     // general kernel, discovery from explicit states: work item i starts at states[i * nw ..] (no enumeration)
     const uint32_t* states;
+};
+
+// Cube collapse, ordering heuristic: how long does a flip of each relevant digit stay visible?  One thread per
+// (digit, trial) steps the block's base state with a pseudo-random assignment of the free digits, once with
+// the digit clear and once set, until the two trajectories meet (bsx_pool.hip: k_digit_lifetimes).  Digits
+// whose influence dies first become the lowest class-index bits, so that the classes that will merge sit
+// next to each other.  Only the enumeration ORDER depends on this, never a result.
+constexpr uint32_t kLifeTrials = 16;
+constexpr uint32_t kLifeSteps = 48;
+struct LifetimeParams {
+    DevNet net;
+    uint32_t fixmask[kMaxW32], fixval[kMaxW32];
+    uint32_t base[kMaxW32];         // the block's fixed bits (free bits zero)
+    uint32_t free_mask[kMaxW32];    // node bits of its free digits
+    uint32_t n_digits;              // <= 64
+    uint32_t pad;
+    uint32_t node[64];              // node of each relevant digit
+    uint32_t* out;                  // [n_digits] sum over the trials of the steps until the flip has died out
 };
 
 struct HitRec { uint64_t offset; uint64_t t; };

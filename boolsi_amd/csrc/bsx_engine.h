@@ -76,6 +76,7 @@ struct bsx_engine {
     uint64_t table_slots = 0;
     bool table_dirty = false;
     bsx::DevBuf<uint32_t> d_strag;
+    bsx::DevBuf<uint32_t> d_life;       // cube collapse: per-digit influence lifetimes (ordering heuristic)
     bsx::DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
 
     // host copies for the bit-sliced simulate kernel's node descriptors

@@ -52,8 +52,10 @@ constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
 // OR the digits of `d` into `s` along the deposit plan (init_problem_simple without the origin).  With a
 // wave-uniform `d` this is scalar work.
 template <int NW>
-__device__ __forceinline__ void deposit_runs(const DevSpace& sp, uint64_t d, uint32_t (&s)[NW]) {
-    for (uint32_t r = 0; r < sp.n_runs; ++r) {
+__device__ __forceinline__ void deposit_runs(const DevSpace& sp, uint64_t d, uint32_t (&s)[NW], uint32_t run_first = 0,
+                                             uint32_t run_end = 0xFFFFFFFFu) {
+    const uint32_t end = run_end < sp.n_runs ? run_end : sp.n_runs;
+    for (uint32_t r = run_first; r < end; ++r) {
         const uint32_t desc = sp.deposit[2 * r], mask = sp.deposit[2 * r + 1];
         const uint32_t piece = ((uint32_t)(d >> (desc & 63u)) & mask) << ((desc >> 16) & 31u);
         const uint32_t word = (desc >> 8) & 7u;
@@ -156,6 +158,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
     for (int w = 0; w < NW; ++w) lane_part[w] = 0;
     if constexpr (cube) deposit_runs<NW>(P.sp, (uint64_t)lane, lane_part);
+    // ... and bits 12 and up change once per 4096 classes: their deposit is kept (scalar registers) with its tag
+    uint32_t u_hi[NW];
+    uint64_t u_hi_tag = ~0ull;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) u_hi[w] = 0;
 
     const uint32_t cap_rel = (P.cap_rel_inf || P.max_t - tp >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)(P.max_t - tp);
 
@@ -287,10 +294,17 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             live = lane < n;
             base = (uint32_t)q.next;
             if constexpr (cube) {                           // q.next is a multiple of 64 and the class index starts at 0
+                // (a cube's plan has one run per relevant digit, so run r is class-index bit r)
+                if ((q.next >> 12) != u_hi_tag) {           // uniform, rare
+                    u_hi_tag = q.next >> 12;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) u_hi[w] = P.sp.origin[w];
+                    deposit_runs<NW>(P.sp, q.next & ~0xFFFull, u_hi, 12u);
+                }
                 uint32_t u[NW];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) u[w] = P.sp.origin[w];
-                deposit_runs<NW>(P.sp, q.next, u);
+                for (int w = 0; w < NW; ++w) u[w] = u_hi[w];
+                deposit_runs<NW>(P.sp, q.next & 0xFC0ull, u, 6u, 12u);
 #pragma unroll
                 for (int w = 0; w < NW; ++w) A[w] = u[w] | lane_part[w];
             } else {
@@ -494,6 +508,53 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), (int)lane);
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, (int)lane);
     wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, (int)lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_digit_lifetimes (bsx_device.h: LifetimeParams): ordering heuristic of the cube collapse.
+template <int NW, int K, int LM>
+__global__ __launch_bounds__(1024) void k_digit_lifetimes(const LifetimeParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* smem_free;
+    const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
+    const uint32_t digit = threadIdx.x / kLifeTrials, trial = threadIdx.x % kLifeTrials;
+    if (digit >= P.n_digits) return;
+    uint32_t fm[NW], fv[NW], x[NW], y[NW];
+    uint32_t any_fixed = 0;
+    const uint32_t node = P.node[digit];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        fm[w] = P.fixmask[w]; fv[w] = P.fixval[w]; any_fixed |= fm[w];
+        uint32_t rnd = (trial * 0x9E3779B1u + (uint32_t)w * 0x85EBCA6Bu + 0x27D4EB2Fu) * 0xC2B2AE35u;
+        rnd ^= rnd >> 15; rnd *= 0x2C1B3C6Du; rnd ^= rnd >> 12;
+        const uint32_t bit = ((node >> 5) == (uint32_t)w) ? 1u << (node & 31) : 0u;
+        x[w] = (P.base[w] | (trial ? rnd & P.free_mask[w] : 0u)) & ~bit;       // trial 0: every other free digit 0
+        y[w] = x[w] | bit;
+    }
+    uint32_t t = 0;
+    while (t < kLifeSteps && !eq_words<NW>(x, y)) {
+        uint32_t nx[NW], ny[NW];
+        net_step<NW, K>(nv, x, fm, fv, nx, any_fixed != 0);
+        net_step<NW, K>(nv, y, fm, fv, ny, any_fixed != 0);
+        copy_words<NW>(x, nx); copy_words<NW>(y, ny);
+        ++t;
+    }
+    atomicAdd(&P.out[digit], t);
+}
+
+template <int NW, int K>
+static hipError_t launch_life_nk(int lut_mode, dim3, size_t shmem, hipStream_t st, const LifetimeParams& P) {
+    const void* fn;
+    BSX_KERNEL_FOR_MODE(k_digit_lifetimes, NW, K, lut_mode, fn);
+    if (!fn) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    void* args[] = {const_cast<LifetimeParams*>(&P)};
+    return hipLaunchKernel(fn, dim3(1), dim3(1024), args, shmem, st);
+}
+hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P) {
+    const dim3 grid(1);
+    BSX_DISPATCH(launch_life_nk)
 }
 
 template <int NW, int K>

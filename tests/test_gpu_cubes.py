@@ -72,12 +72,13 @@ def test_cubes_vs_oracle_aligned_ragged_and_capped(eng):
     same_as_oracle(eng, net, space, 0, 1 << 23)                              # the block at digit value 0
 
 
-@pytest.mark.parametrize('text,bits', [(synth.config3_yaml(), 32), (synth.network_yaml(128, 2, 129), 128),
-                                       (synth.network_yaml(48, 3, 481), 48)])
-def test_cubes_vs_oracle_other_networks(eng, text, bits):
+@pytest.mark.parametrize('name,text,bits,log2n', [('config3', synth.config3_yaml(), 32, 22), ('n128_k2', synth.network_yaml(128, 2, 129), 128, 22),
+                                                  ('n48_k3', synth.network_yaml(48, 3, 481), 48, 18)],      # (K = 3: long transients, slow oracle)
+                         ids=['config3', 'n128_k2', 'n48_k3'])
+def test_cubes_vs_oracle_other_networks(eng, name, text, bits, log2n):
     net, space = setup(eng, text)
-    same_as_oracle(eng, net, space, 0, 1 << 22)
-    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << 21) + 99)
+    same_as_oracle(eng, net, space, 0, 1 << log2n)
+    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << (log2n - 1)) + 99)
 
 
 def test_first_contact_with_an_attractor_in_a_cube_pass(eng):

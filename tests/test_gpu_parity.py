@@ -158,7 +158,7 @@ def _same_attract(eng, orc, first, count, max_t, max_len=None):
     ('synth_n128', synth.network_yaml(128, 2, 129), 128),
     ('synth_n256_k3', synth.network_yaml(256, 3, 256), 256),
     ('synth_n48_k6', synth.network_yaml(48, 6, 48), 48),
-])
+], ids=lambda v: v if isinstance(v, str) and len(v) < 30 else None)
 def test_attract_vs_oracle_slices(eng, name, text, space_bits):
     cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 4096)
     rng = random.Random(hash(name) & 0xFFFF)

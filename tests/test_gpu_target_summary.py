@@ -37,7 +37,7 @@ def test_summary_equals_the_hit_list(eng, case):
     cfg, net, space = compile_case(case)
     eng.set_problem(net, space)
     mask, code = target_words(cfg, net)
-    n = space.n_problems
+    n = min(space.n_problems, 1 << 20)          # (config 4 has 2^31 problems: its full size is the next test)
     max_t = t_of(case['max_t'])
     hits, st = eng.target(0, n, max_t, mask, code)
     bins = 16
