@@ -502,11 +502,16 @@ enum PassKind { kPassGeneral = 0, kPassLean = 1, kPassPool = 2 };
 // to hold what the journal holds (4 slots per state keeps probe chains short); a smaller mirror leaves
 // the LDS to more workgroups.  The general kernel inserts while it runs and keeps the full size.
 int mirror_slots_for(bsx_handle h, uint32_t* slots_out) {
-    // 4 slots per state keep probe chains short; a cube pass adds one representative entry per state
-    const uint64_t want = (h->cube_mirror ? 8 : 4) * h->journal_states;
+    // At least 2 slots per entry (a cube pass adds one representative entry per state), 4 where that still lets
+    // two workgroups share a CU's LDS: at n = 64 a pool workgroup is 75.7 KiB + mirror, so a 256-slot mirror
+    // already halves the occupancy (measured: 3 instead of 6 waves per SIMD, profiles/r02_pmc notes).
+    const uint64_t entries = (h->cube_mirror ? 2 : 1) * h->journal_states;
     uint32_t slots = 64;
-    while (slots < want && slots < h->cache_lds_slots) slots *= 2;
+    while (slots < 2 * entries && slots < h->cache_lds_slots) slots *= 2;
+    const size_t fixed = h->shmem + 32 + pool_extra_bytes(h->net.nw);
+    while (slots < 4 * entries && slots < h->cache_lds_slots && fixed + (size_t)2 * slots * h->cache_stride <= 80 * 1024) slots *= 2;
     h->mirror_slots = *slots_out = std::min(slots, h->cache_lds_slots);
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] mirror: %llu cycle states cached, %u slots\n", (unsigned long long)h->journal_states, *slots_out);
     return BSX_OK;
 }
 
@@ -958,13 +963,16 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // ---- cube collapse: aligned blocks of >= 2^kCubeMinBits problems are enumerated by their relevant digits
     // only (see build_cube).  Everything before the first / after the last such block goes through the tiles.
     const char* cubes_env = std::getenv("BSX_CUBES");                     // "0": off (A/B runs, tests)
-    const bool cubes_ok = use_fast && merge_mode == 2 && !per_problem && h->sp.tp_origin == 0 &&
+    // (a warm-up under origin perturbations is fine: the first update still depends on the relevant digits only)
+    const bool cubes_ok = use_fast && merge_mode == 2 && !per_problem &&
                           !(cubes_env && cubes_env[0] == '0') && h->sp.n_any >= kCubeMinBits;
     auto run_cube = [&](const Cube& c, bool& collapsed) -> int {
         collapsed = false;
         const uint32_t nw = h->net.nw, rec_words = nw + 3;
         const uint32_t r_bits = (uint32_t)c.rel.size();
-        const uint32_t cap_rel32 = (max_t == BSX_T_INF || max_t >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)max_t;
+        const uint64_t tp = h->sp.tp_origin;            // the search starts at s(T_p); class times count from there
+        const uint64_t cap_rel = max_t == BSX_T_INF ? BSX_T_INF : max_t - tp;
+        const uint32_t cap_rel32 = (cap_rel == BSX_T_INF || cap_rel >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)cap_rel;
         const uint64_t list_cap = 1ull << 20;                   // unresolved classes per pass
         if (h->d_strag.n < list_cap * rec_words) HIPCHK(h, h->d_strag.alloc(list_cap * rec_words));
         for (int attempt = 0; attempt < 16; ++attempt) {
@@ -973,7 +981,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             if (int rc = lean_mirror_slots(h, &slots)) return rc;
             uint64_t states = 0;
             for (const CycleRecord& jr : h->h_journal) states += jr.length;
-            if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 8 * states > h->cache_lds_slots) return BSX_OK;
+            if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 4 * states > h->cache_lds_slots) return BSX_OK;
             AttractParams Q = P;
             Q.sp = c.sp;
             Q.count = 1ull << r_bits;
@@ -1009,6 +1017,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 HIPCHK(h, d_res.alloc(n_unres));
                 AttractParams S = P;
                 S.sp = c.sp;
+                S.sp.tp_origin = 0;                     // the listed states are past the warm-up
                 S.count = n_unres;
                 S.states = d_states.p;
                 S.per_problem = d_res.p;
@@ -1025,9 +1034,9 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                     const ProblemRec32& pr = res[i];
                     if (!pr.found) { extra_none += m; extra_ref += m * max_t; continue; }      // (finite cap, or the step limit was hit)
                     if (pr.trajectory_l == 0) { repeat = true; break; }                          // on a cycle: members' mu unknown
-                    const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length;
-                    const bool found = max_t == BSX_T_INF || mu + lam <= max_t;
-                    extra_ref += found ? m * (mu + lam) : m * max_t;
+                    const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length, traj = tp + mu;
+                    const bool found = cap_rel == BSX_T_INF || mu + lam <= cap_rel;
+                    extra_ref += found ? m * (traj + lam) : m * max_t;
                     if (!found || lam > max_len) { extra_none += m; continue; }
                     const Key8 key = key8(pr.key);
                     auto it = pass_table.find(key);
@@ -1039,8 +1048,8 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                     }
                     bsx_attr_rec& e = it->second;
                     e.count += m;
-                    e.sum_l += m * mu;
-                    const unsigned __int128 sq = (unsigned __int128)(m * mu) * mu + e.sum_l2_lo;
+                    e.sum_l += m * traj;
+                    const unsigned __int128 sq = (unsigned __int128)(m * traj) * traj + e.sum_l2_lo;
                     e.sum_l2_lo = (uint64_t)sq;
                     e.sum_l2_hi += (uint64_t)(sq >> 64);
                 }

@@ -44,7 +44,7 @@ constexpr int kPoolBlock = 768;
 constexpr int kPoolWaves = kPoolBlock / 64;
 constexpr uint32_t kPoolCap = 112;              // classes per wave (ring buffer; > 64 + what a fresh stage leaves)
 constexpr uint32_t kPoolGroup = 64;             // problems loaded together = lanes
-constexpr uint32_t kPoolSlots = 256;            // merge slots per wave (one-byte lane ids); 128 lost a third of the pool-stage merges to slot collisions
+constexpr uint32_t kPoolSlots = 128;            // merge slots per wave (one-byte lane ids; 256 slots: 2 % fewer updates, not worth 1.5 KiB of LDS)
 
 constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // state, group base, members lo/hi, time
 constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     uint32_t* keytab = lamtab + kAccs;
     constexpr uint32_t kWaveWords = kPoolCap * R + 128 + kPoolSlots / 4;
     static_assert(kAccs % 2 == 0 && kWaveWords % 2 == 0, "64-bit LDS atomics need 8-byte aligned tables");
-    uint32_t* wave_base = keytab + ((kAccs * NW + 1u) & ~1u) + wave * kWaveWords;
+    uint32_t* midtab = keytab + ((kAccs * NW + 1u) & ~1u);      // cube pass: deposits of class-index bits 6..11, [64][NW]
+    uint32_t* wave_base = midtab + 64 * NW + wave * kWaveWords;
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
     lds_vu32* const pool = (lds_vu32*)(__attribute__((address_space(3))) uint32_t*)wave_base;
@@ -128,6 +129,16 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         }
     }
     __syncthreads();
+    if constexpr (cube) {
+        for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) {
+            uint32_t m[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) m[w] = 0;
+            deposit_runs<NW>(P.sp, (uint64_t)i << 6, m, 6u, 12u);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) midtab[i * NW + w] = m[w];
+        }
+    }
     // cube pass: cached cycle states inside the block get a second mirror entry, their class representative
     if (cube && threadIdx.x == 0) {
         uint32_t n_in = 0;
@@ -151,7 +162,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         lc[1] = n_in;
     }
     __syncthreads();
-    const bool t0_lookup = cube && __builtin_amdgcn_readfirstlane(lc[1]) != 0;     // uniform: some member may have mu = 0
+    // uniform: some member may have mu = 0 (with a warm-up the search starts at s(T_p), which all members share)
+    const bool t0_lookup = cube && !has_warmup && __builtin_amdgcn_readfirstlane(lc[1]) != 0;
     // cube pass: a wave's 64 classes differ in the six lowest relevant digits only; where those land in the
     // state is the same in every iteration, the rest of the class index is wave-uniform (scalar deposit)
     uint32_t lane_part[NW];
@@ -301,12 +313,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     for (int w = 0; w < NW; ++w) u_hi[w] = P.sp.origin[w];
                     deposit_runs<NW>(P.sp, q.next & ~0xFFFull, u_hi, 12u);
                 }
-                uint32_t u[NW];
+                const uint32_t mid = (((uint32_t)q.next >> 6) & 63u) * NW;     // uniform: one broadcast read per word
 #pragma unroll
-                for (int w = 0; w < NW; ++w) u[w] = u_hi[w];
-                deposit_runs<NW>(P.sp, q.next & 0xFC0ull, u, 6u, 12u);
-#pragma unroll
-                for (int w = 0; w < NW; ++w) A[w] = u[w] | lane_part[w];
+                for (int w = 0; w < NW; ++w) A[w] = u_hi[w] | midtab[mid + w] | lane_part[w];
             } else {
                 init_problem_simple<NW>(P.sp, q.next + lane, A);
             }
@@ -602,7 +611,8 @@ hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int
 
 // bytes of LDS behind the cache mirror: per-attractor tables + per-wave pool, accumulators and id slots
 size_t pool_extra_bytes(uint32_t nw) {
-    const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 8 + 8 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16;
+    const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 8 + 8 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16 +
+                          (size_t)64 * nw * 4;      // + the cube pass's mid-bit deposit table
     const size_t per_wave = ((size_t)kPoolCap * pool_rec_words(nw) + 128 + kPoolSlots / 4) * 4;
     return tables + (size_t)kPoolWaves * per_wave;
 }

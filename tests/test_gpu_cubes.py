@@ -93,6 +93,16 @@ def test_first_contact_with_an_attractor_in_a_cube_pass(eng):
     assert rows(got.table) == rows(plain.table) and got.stats['state_steps'] == plain.stats['state_steps']
 
 
+def test_cubes_with_a_warm_up_under_perturbations(eng):
+    """Origin perturbations (cambium2: ETHL := 1 at t = 2..5; a synthetic schedule): the first update still
+    depends on the relevant digits only and the search starts at s(T_p), which all members of a class share."""
+    text = synth.network_yaml(40, 2, 401, perturbations={3: {'1': '1-3'}, 17: {'0': '2, 5'}}, fixed={9: '1'})
+    for max_t in (4096, 12):
+        net, space = setup(eng, text, max_t)
+        same_as_oracle(eng, net, space, 0, 1 << 22, max_t=max_t)
+        same_as_oracle(eng, net, space, (1 << 30) + 777, (1 << 21) + 5, max_t=max_t)
+
+
 def test_members_that_are_cycle_states_themselves(eng):
     """Rules x0..x2 keep their state, x5 is constant 1, the rest constant 0: eight fixed points, each the ONLY
     mu = 0 member of its class, and (bit 5 set) not its class representative."""
