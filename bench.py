@@ -143,7 +143,7 @@ def main():
                                    '-t 4096, 2^{} consecutive problem indices per GPU per step'.format(args.log2_batch),
                        'n_nodes': n, 'problems_per_gpu_per_step': batch, 'max_t': MAX_T,
                        'partition': 'range x{}'.format(comm.world),
-                       'merge': 'one RCCL all-gather after the last step' if comm.world > 1 else 'none (1 GPU)'},
+                       'merge': ('one all-gather after the last step, data plane: ' + str(comm.backend)) if comm.world > 1 else 'none (1 GPU)'},
             'value_counts': 'executed network updates x n nodes (work skipped by the cycle cache / class pooling is not counted)',
             'attractors_per_s': problems / elapsed,
             'executed_node_updates_per_s': tot_exec * n / elapsed,

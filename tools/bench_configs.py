@@ -84,7 +84,7 @@ def main():
                 roof = roofline(fg_bytes, st['kernel_ms'], note='array bytes the {} passes stream through HBM ({} doubling + {} jump rounds), '
                                 'a random gather counted at its 4 or 8 useful bytes'.format(st['kernel_launches'], doubling, jumps))
             else:
-                run_attract_range(eng, first, min(count, 1 << 22), max_t)             # warm the cycle cache
+                run_attract_range(eng, first, count if count <= 1 << 32 else count >> 4, max_t)     # warm the cycle cache and the scratch buffers
                 t0 = time.perf_counter()
                 merged, none, st = run_attract_range(eng, first, count, max_t)
                 dt = time.perf_counter() - t0
@@ -144,6 +144,20 @@ def main():
         dtc = time.perf_counter() - t0
         cpu = {'value': (1 << 13) * 10000 * 128 / dtc, 'unit': 'node-state-updates/s', 'cores': CORES, 'kind': 'port',
                'sample': 'first 2^13 problems x 10000 steps, CPU oracle, {:.1f} s'.format(dtc)}
+    def sim_roofline(label, st):
+        rate = st['executed_steps'] * 128 / (st['kernel_ms'] * 1e-3)
+        if label.startswith('bit-sliced'):
+            # The state matrix stays in LDS for all 10 000 steps (temporal blocking factor T = 10 000), so SURVEY 8(d)'s
+            # streaming basis would give a figure above 1.  What bounds the kernel is VALU issue: one v_bfi per mux and
+            # 32 trajectories, 2^K - 1 = 7 muxes per node update -> 7/32 lane-instructions per node update; the chip
+            # issues 1024 SIMDs x 64 lanes x clock / 4 cycles per wave-instruction.
+            peak = 1024 * 64 * 2.1e9 / 4 / (7 / 32)
+            return {'bound': 'valu', 'achieved': rate, 'peak': peak, 'unit': 'node-updates/s', 'frac': rate / peak, 'traffic': None,
+                    'basis': 'VALU issue bound of the mux tree (7 v_bfi per 32 node updates at K = 3, 2.1 GHz); the state matrix never '
+                             'leaves LDS (T = 10000), HBM traffic is the initial / final states only',
+                    'survey_8d_streaming_equivalent_GBps': rate * 0.25 / 1e9}
+        return roofline(st['executed_steps'] * 128 * 0.25, st['kernel_ms'], note='0.25 B per node update (SURVEY 8d)')
+
     count = 1 << (16 if quick else 20)
     for label, kw, env in (('bit-sliced kernel, final states + digests', dict(digest=True), None),
                            ('bit-sliced kernel, final states only', dict(digest=False), None),
@@ -160,8 +174,7 @@ def main():
               'node_updates_per_s': st['state_steps'] * 128 / dt,
               'kernel_node_updates_per_s': st['state_steps'] * 128 / (st['kernel_ms'] * 1e-3),
               'seconds_for_2^26': dt * (1 << 26) / count,
-              'roofline': roofline(st['executed_steps'] * 128 * 0.25, st['kernel_ms'],
-                                   note='0.25 B per node update (SURVEY 8d); the state matrix lives in LDS, so a normalised rate'),
+              'roofline': sim_roofline(label, st),
               'cpu_baseline': cpu})
     if '--full-config5' in sys.argv:
         # the whole of config 5 on one GPU: 2^26 problems x 10000 steps, digests only, in slices of 2^22
@@ -175,7 +188,7 @@ def main():
         dt = time.perf_counter() - t0
         emit({'config': 'config5 FULL: 2^26 problems x 10000 steps, digests', 'mode': 'simulate', 'n': 128, 'problems': 1 << 26, 'wall_s': dt,
               'kernel_ms': kms, 'xor_of_all_digests': int(acc), 'node_updates_per_s': (1 << 26) * 10000 * 128 / dt,
-              'roofline': roofline((1 << 26) * 10000 * 128 * 0.25, kms, note='0.25 B per node update (SURVEY 8d)')})
+              'roofline': sim_roofline('bit-sliced', {'executed_steps': (1 << 26) * 10000, 'kernel_ms': kms})})
     eng.close()
 
 

@@ -41,15 +41,16 @@ if 'GRBM_GUI_ACTIVE' in c:
         bound['salu_busy_frac'] = 4 * c['SQ_ACTIVE_INST_SCA'] / (simds * cycles)
     if 'SQ_LDS_IDX_ACTIVE' in c:
         bound['lds_busy_frac'] = c['SQ_LDS_IDX_ACTIVE'] / (cus * cycles)
+        if bound['lds_busy_frac'] > 1.0:
+            bound['lds_note'] = ('above 1: the counters come from separate runs (clock and tile mix differ by a few percent) '
+                                 'and the LDS pipeline is busy for the whole launch -- read as saturated')
     if 'SQ_LDS_BANK_CONFLICT' in c and 'SQ_LDS_IDX_ACTIVE' in c:
         bound['lds_conflict_share'] = c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE']
     if 'SQ_WAIT_ANY' in c and 'SQ_WAVE_CYCLES' in c:
         bound['wave_wait_frac'] = c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']
-    if 'SQ_WAVE_CYCLES' in c:
-        bound['waves_per_simd_avg'] = 4 * c['SQ_WAVE_CYCLES'] / (simds * cycles)
     for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS'):
         if k in c:
             bound[k.lower() + '_per_launch'] = c[k]
-    bound['reading'] = 'fractions of the launch during which the unit is busy, device average; the larger of valu_busy_frac and lds_busy_frac is the bound'
+    bound['reading'] = 'fractions of the launch during which the unit is busy, device average; the largest one is the bound'
     out['issue_bound'] = bound
 print(json.dumps(out, indent=1))
