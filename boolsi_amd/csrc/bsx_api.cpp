@@ -268,7 +268,7 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
         if (h->pool_ok) HIPCHK(h, configure_attract_pool((int)nw, (int)k_mux, h->lut_mode, std::min<size_t>(pool_max, 160 * 1024 - 1024), &blocks));
     }
     if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] network: nw %u k_mux %u lut mode %d (0 L2 bytes, 1 LDS bytes, 2 LDS nibbles) shmem %zu attract shmem %zu lean blocks/CU %d\n", nw, k_mux, (int)h->lut_mode, h->shmem, h->shmem_attract, h->lean_blocks_per_cu);
-    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_mode, h->shmem + 16 + kTargetHistBins * 4));
+    HIPCHK(h, configure_target((int)nw, (int)k_mux, h->lut_mode, h->shmem + 16 + kTargetHistBins * 8));
     HIPCHK(h, configure_simulate((int)nw, (int)k_mux, h->lut_mode, h->shmem));
     h->have_net = true;
     return BSX_OK;
@@ -339,6 +339,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
         for (const auto& e : ordered) { h->h_sched.push_back(e[0]); h->h_sched.push_back(e[1]); h->h_sched.push_back(e[2]); }
     }
     h->h_any = any;
+    h->h_fv = fv;
     HIPCHK(h, h->d_any.upload(any));
     HIPCHK(h, h->d_fv.upload(fv));
     HIPCHK(h, h->d_pv.upload(pv));
@@ -639,7 +640,8 @@ struct Cube {
     bool ok = false;            // false: more deposit runs than the kernels take
 };
 
-void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c) {
+void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const uint32_t* fixmask = nullptr) {
+    if (!fixmask) fixmask = h->sp.fixmask;      // (target passes: the fixed nodes of the block's fixed-node variant)
     const uint32_t n = h->n_nodes, nw = h->net.nw;
     c.d_lo = d_lo; c.a = a; c.rel.clear(); c.ok = false;
     uint32_t base[kMaxW32];     // origin bits + the block's fixed digits
@@ -651,7 +653,7 @@ void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c) {
         else if ((d_lo >> j) & 1ull) base[node >> 5] |= 1u << (node & 31);
     }
     for (uint32_t i = 0; i < n; ++i) {
-        if ((h->sp.fixmask[i >> 5] >> (i & 31)) & 1u) continue;
+        if ((fixmask[i >> 5] >> (i & 31)) & 1u) continue;
         const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
         const uint32_t* preds = h->h_pred_idx.data() + h->h_pred_offsets[i];
         if (k > (uint32_t)kMaxMuxK) {                    // wide rule: every free input counts (conservative)
@@ -1134,7 +1136,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
 static int launch_target_pass(bsx_handle h, const bsx_index* first, uint64_t skip, uint64_t count, uint64_t max_t,
                               const uint64_t* mask_words, const uint64_t* code_words, uint32_t* d_thit,
                               unsigned long long* d_hist, uint32_t hist_bins, Counters& ctr, float& ms) {
-    const size_t shmem = h->shmem + (d_hist ? 16 + (size_t)hist_bins * 4 : 0);
+    const size_t shmem = h->shmem + (d_hist ? 16 + (size_t)hist_bins * 8 : 0);
     const Launch L = plan_persistent(h, count, shmem);
     TargetParams P{};
     P.net = h->net;
@@ -1409,33 +1411,133 @@ extern "C" int bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint
     if (count == 0) return BSX_OK;
     if (count > (1ull << 40)) return fail(h, BSX_ERR_INVALID, "at most 2^40 problems per call");
 
-    DevBuf<unsigned long long> d_hist;
-    if (hist_bins) {
-        HIPCHK(h, d_hist.alloc(hist_bins));
-        HIPCHK(h, hipMemsetAsync(d_hist.p, 0, hist_bins * sizeof(unsigned long long), h->stream));
-    }
+    DevBuf<unsigned long long> d_hist;              // (one bin even if the caller wants none: the kernels count into it)
+    HIPCHK(h, d_hist.alloc(std::max<uint32_t>(hist_bins, 1)));
+    HIPCHK(h, hipMemsetAsync(d_hist.p, 0, std::max<uint32_t>(hist_bins, 1) * sizeof(unsigned long long), h->stream));
     // The hit list is the first `cap` hits in index order (what -n keeps, simulate.py:163-164): problems are
     // scanned in pieces with a dense t_hit array until the list is full, the rest of the range is only counted.
     uint64_t done = 0, listed = 0, total = 0, steps_ref = 0, steps_exec = 0;
     double kernel_ms = 0.0;
     uint32_t launches = 0, limit_hits = 0;
     DevBuf<uint32_t> d_thit;
-    while (done < count) {
-        const bool listing = listed < cap;
-        const uint64_t piece = std::min<uint64_t>(count - done, listing ? std::max<uint64_t>(1ull << 22, 4 * (cap - listed)) : (1ull << 32));
-        if (listing) HIPCHK(h, d_thit.reserve(std::min<uint64_t>(piece, 1ull << 32)));
-        const uint64_t n = listing ? std::min<uint64_t>(piece, d_thit.n) : piece;
+    auto plain_pass = [&](uint64_t at, uint64_t n, bool listing) -> int {
         Counters ctr{};
         float ms = 0.f;
-        if (int rc = launch_target_pass(h, first, done, n, max_t, mask_words, code_words, listing ? d_thit.p : nullptr,
-                                        hist_bins ? d_hist.p : nullptr, hist_bins, ctr, ms)) return rc;
+        if (int rc = launch_target_pass(h, first, at, n, max_t, mask_words, code_words, listing ? d_thit.p : nullptr,
+                                        d_hist.p, hist_bins ? hist_bins : 1, ctr, ms)) return rc;
         if (listing) {
-            if (int rc = compact_hits(h, d_thit.p, n, ctr.log_cursor, done, hits + listed, cap - listed)) return rc;
+            if (int rc = compact_hits(h, d_thit.p, n, ctr.log_cursor, at, hits + listed, cap - listed)) return rc;
             listed += std::min<uint64_t>(ctr.log_cursor, cap - listed);
         }
         total += ctr.log_cursor; steps_ref += ctr.steps_ref; steps_exec += ctr.steps_exec;
         kernel_ms += ms; ++launches; limit_hits += ctr.step_limit_hits;
+        return BSX_OK;
+    };
+    // the listed hits first: dense pieces of the range
+    while (done < count && listed < cap) {
+        const uint64_t piece = std::min<uint64_t>(count - done, std::max<uint64_t>(1ull << 22, 4 * (cap - listed)));
+        HIPCHK(h, d_thit.reserve(std::min<uint64_t>(piece, 1ull << 32)));
+        const uint64_t n = std::min<uint64_t>(piece, d_thit.n);
+        if (int rc = plain_pass(done, n, true)) return rc;
         done += n;
+    }
+    // the rest is only counted: cube passes over the aligned blocks of every fixed-node variant (the first update
+    // of a block depends on its relevant digits only, build_cube), plain passes over what is left
+    const char* cubes_env = std::getenv("BSX_CUBES");
+    const bool cubes_ok = !(cubes_env && cubes_env[0] == '0') && h->sp.n_any >= kCubeMinBits && h->sp.n_any <= 64 &&
+                          (h->sp.identity_any || h->sp.n_runs) && !h->sp.n_pv && !h->sp.tp_origin && !h->variant_count_saturated;
+    while (done < count) {
+        if (!cubes_ok) {
+            const uint64_t n = std::min<uint64_t>(count - done, 1ull << 32);
+            if (int rc = plain_pass(done, n, false)) return rc;
+            done += n;
+            continue;
+        }
+        // (variant, digit value) of problem first + done; the segment of the range inside this variant
+        const uint32_t n_any = h->sp.n_any;
+        const unsigned __int128 space = (unsigned __int128)1 << n_any;
+        const unsigned __int128 pos = (unsigned __int128)first->init_digits[0] + done;
+        const uint64_t variant = first->variant + (uint64_t)(pos >> n_any);
+        const unsigned __int128 digit = pos & (space - 1);
+        const uint64_t seg = (uint64_t)std::min<unsigned __int128>(count - done, space - digit);
+        uint32_t vfm[kMaxW32], vfv[kMaxW32];
+        for (int w = 0; w < kMaxW32; ++w) { vfm[w] = h->sp.fixmask[w]; vfv[w] = h->sp.fixval[w]; }
+        {   // the variant's fixed nodes (batching.py:171-175, 212-229)
+            uint64_t v = variant;
+            for (size_t j = 0; j + 1 < h->h_fv.size(); j += 2) {
+                const uint32_t node = h->h_fv[j], range = h->h_fv[j + 1];
+                const uint32_t radix = range == BSX_RANGE_MAYBE_TRUE_OR_FALSE ? 3 : 2, dg = (uint32_t)(v % radix);
+                v /= radix;
+                int st = -1;
+                if (range == BSX_RANGE_MAYBE_FALSE) st = dg ? 0 : -1;
+                else if (range == BSX_RANGE_MAYBE_TRUE) st = dg ? 1 : -1;
+                else if (range == BSX_RANGE_TRUE_OR_FALSE) st = dg ? 1 : 0;
+                else st = dg == 0 ? -1 : (dg == 1 ? 0 : 1);
+                if (st >= 0) {
+                    vfm[node >> 5] |= 1u << (node & 31);
+                    vfv[node >> 5] = (vfv[node >> 5] & ~(1u << (node & 31))) | ((uint32_t)st << (node & 31));
+                }
+            }
+        }
+        const unsigned __int128 unit = (unsigned __int128)1 << kCubeMinBits;
+        const unsigned __int128 seg_end = digit + seg;
+        unsigned __int128 at = (digit + unit - 1) / unit * unit;
+        const unsigned __int128 body_end = seg_end / unit * unit;
+        if (at >= body_end) { if (int rc = plain_pass(done, seg, false)) return rc; done += seg; continue; }
+        if (at > digit) { if (int rc = plain_pass(done, (uint64_t)(at - digit), false)) return rc; done += (uint64_t)(at - digit); }
+        while (at < body_end) {
+            uint32_t a_bits = std::min<uint32_t>(kCubeMaxBits, n_any);
+            while (a_bits > kCubeMinBits && ((at & (((unsigned __int128)1 << a_bits) - 1)) != 0 || at + ((unsigned __int128)1 << a_bits) > body_end)) --a_bits;
+            const uint64_t block = 1ull << a_bits;
+            Cube c;
+            build_cube(h, (uint64_t)at, a_bits, c, vfm);
+            if (c.ok && c.rel.size() + 2 <= a_bits) {
+                plan_cube(h, c);
+                TargetParams P{};
+                P.net = h->net;
+                P.sp = c.sp;
+                P.sp.n_fv = 0;                              // the variant is baked into the masks
+                for (int w = 0; w < kMaxW32; ++w) { P.sp.fixmask[w] = vfm[w]; P.sp.fixval[w] = vfv[w]; }
+                P.count = 1ull << c.rel.size();
+                P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
+                P.max_t = max_t;
+                uint32_t in_mask = 0;
+                for (uint32_t w = 0; w < h->w64; ++w)
+                    for (int half = 0; half < 2 && 2 * w + half < (uint32_t)kMaxW32; ++half) {
+                        const uint32_t m32 = (uint32_t)(mask_words[w] >> (32 * half)), c32 = (uint32_t)(code_words[w] >> (32 * half));
+                        const uint32_t idx = 2 * w + half;
+                        P.tmask[idx] = m32; P.tcode[idx] = c32;
+                        P.rep_mask[idx] = m32 & ~c.umask[idx];
+                        P.rep_code[idx] = c32 & m32 & ~c.umask[idx];
+                        in_mask += (uint32_t)__builtin_popcount(m32 & c.umask[idx]);
+                    }
+                P.cube = 1;
+                P.cube_shift = a_bits - (uint32_t)c.rel.size();
+                P.cube_t0_shift = in_mask;
+                P.ctr = h->d_ctr.p;
+                P.t_hit = nullptr;
+                P.hist = d_hist.p;
+                P.hist_bins = hist_bins ? hist_bins : 1;
+                const size_t shmem = h->shmem + 16 + (size_t)P.hist_bins * 8;
+                const Launch L = plan_persistent(h, P.count, shmem);
+                P.chunk = L.chunk;
+                Counters ctr{};
+                float ms = 0.f;
+                HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+                HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+                HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+                HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+                HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+                total += ctr.log_cursor; steps_ref += ctr.steps_ref; steps_exec += ctr.steps_exec;
+                kernel_ms += ms; ++launches; limit_hits += ctr.step_limit_hits;
+                if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] target cube 2^%u, variant %llu: %zu relevant digits, %.3f ms\n", a_bits, (unsigned long long)variant, c.rel.size(), ms);
+            } else if (int rc = plain_pass(done, block, false)) return rc;
+            done += block;
+            at += block;
+        }
+        if (seg_end > body_end) { if (int rc = plain_pass(done, (uint64_t)(seg_end - body_end), false)) return rc; done += (uint64_t)(seg_end - body_end); }
     }
     if (hist_bins) HIPCHK(h, hipMemcpy(hist, d_hist.p, hist_bins * sizeof(uint64_t), hipMemcpyDeviceToHost));
     *n_hits = total;

@@ -204,8 +204,18 @@ struct TargetParams {
     Counters* ctr;
     uint32_t* t_hit;            // nullable: [count] first hit time per problem, 0xFFFFFFFF = target not reached
     unsigned long long* hist;   // nullable: [hist_bins] hits by first-hit time, last bin = that time or later
-    uint32_t hist_bins;         // <= kTargetHistBins (the workgroups count in LDS first)
+    uint32_t hist_bins;         // <= kTargetHistBins (the workgroups count in LDS first, 64-bit counters)
+    // Cube pass (summary sink only; DESIGN.md "cube collapse"): work items are the assignments of the relevant
+    // digits of an aligned block, each standing for 2^cube_shift problems that share s(1), s(2), ...  Only s(0)
+    // differs between them: a member matches the target at t = 0 iff the representative matches on the target
+    // bits outside the irrelevant free digits (rep_mask / rep_code) and its own irrelevant digits that lie in
+    // the target mask equal the code there -- 2^-cube_t0_shift of the members.
+    uint32_t cube;
+    uint32_t cube_shift;
+    uint32_t cube_t0_shift;
     uint32_t pad;
+    uint32_t rep_mask[kMaxW32];
+    uint32_t rep_code[kMaxW32];
 };
 constexpr uint32_t kTargetHistBins = 2048;
 

@@ -84,6 +84,7 @@ struct bsx_engine {
     std::vector<uint64_t> h_tt0;        // first table word of every node (all of it when k <= 6)
     std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
     std::vector<uint32_t> h_any;        // 'any' nodes in digit order (cube collapse: relevant-digit analysis)
+    std::vector<uint32_t> h_fv;         // fixed-node variations (node, range) in digit order
 
     // problem space
     bool have_space = false;

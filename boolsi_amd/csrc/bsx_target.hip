@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
     const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const int lane = threadIdx.x & 63;
     const bool simple_space = bsx::simple_space(P.sp);
-    uint32_t* hist = smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u);       // LDS, P.hist_bins counters
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem + (((uint32_t)(smem_free - smem) + 3u) & ~3u));   // LDS, P.hist_bins counters
     const uint32_t last_bin = P.hist_bins - 1;
     if (P.hist) {
         for (uint32_t i = threadIdx.x; i < P.hist_bins; i += blockDim.x) hist[i] = 0;
@@ -40,8 +40,10 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
     uint32_t phase = PH_IDLE, t = 0, tp = P.sp.tp_origin, lam = 0, power = 1;
     const uint32_t t_cap = (P.cap_rel_inf || P.max_t >= kStepLimit) ? kStepLimit : (uint32_t)P.max_t;
     uint64_t pv_digits = 0, my_p = 0;
-    uint64_t steps_exec = 0;
-    uint32_t limit_hits = 0, n_hits = 0;
+    uint64_t steps_exec = 0, steps_ref = 0, n_hits = 0;
+    uint64_t members = 1;       // problems this lane's trajectory stands for (cube pass: 2^cube_shift minus the t = 0 hits)
+    uint32_t limit_hits = 0;
+    bool skip0 = false;         // cube pass: the t = 0 check was done per member when the class was set up
     WaveQueue q{0, 0, true};
 
     for (;;) {
@@ -72,6 +74,18 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
                     t = 0; lam = 0; power = 1;
                     copy_words<NW>(B, A);
                     phase = tp > 0 ? PH_WARM : PH_BRENT;
+                    members = 1; skip0 = false;
+                    if (P.cube) {                           // (tp == 0 in cube passes)
+                        uint32_t d = 0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) d |= (A[w] & P.rep_mask[w]) ^ P.rep_code[w];
+                        members = 1ull << P.cube_shift;
+                        const uint64_t at0 = d == 0 ? members >> P.cube_t0_shift : 0ull;
+                        if (at0) { atomicAdd(&hist[0], (unsigned long long)at0); n_hits += at0; }
+                        members -= at0;
+                        skip0 = true;
+                        if (members == 0) phase = PH_IDLE;  // every member hit at t = 0
+                    }
                 }
                 const uint64_t n_idle = (uint64_t)__popcll(idle);
                 q.next += n_idle < avail ? n_idle : avail;
@@ -84,17 +98,18 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
             uint32_t nxt[NW];
             net_step<NW, K>(nv, A, fm, fv, nxt);
             if (phase == PH_BRENT) {
-                const bool reached = target_hit<NW>(A, tm, tc);
+                const bool reached = target_hit<NW>(A, tm, tc) && !(skip0 && t == 0);
                 const bool capped = !reached && t >= t_cap;
                 const uint32_t lam1 = lam + 1;
                 const bool closed = !reached && !capped && eq_words<NW>(nxt, B);     // every state has been checked
                 const bool tele = !closed && lam1 == power;
                 if (reached | capped | closed) {
                     if (P.t_hit) P.t_hit[my_p] = reached ? t : kNotReached;
-                    if (P.hist && reached) atomicAdd(&hist[t < last_bin ? t : last_bin], 1u);
-                    n_hits += reached ? 1u : 0u;
+                    if (P.hist && reached) atomicAdd(&hist[t < last_bin ? t : last_bin], (unsigned long long)members);
+                    n_hits += reached ? members : 0ull;
                     limit_hits += (capped && t_cap == kStepLimit) ? 1u : 0u;
                     steps_exec += t;
+                    steps_ref += members * t;
                     phase = PH_IDLE;
                 } else {
 #pragma unroll
@@ -114,9 +129,9 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
     if (P.hist) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < P.hist_bins; i += blockDim.x)
-            if (hist[i]) atomicAdd(&P.hist[i], (unsigned long long)hist[i]);
+            if (hist[i]) atomicAdd(&P.hist[i], hist[i]);
     }
-    wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps_exec, lane);
+    wave_atomic_add(&P.ctr->steps_ref, (unsigned long long)steps_ref, lane);
     wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)steps_exec, lane);
     wave_atomic_add(&P.ctr->log_cursor, (unsigned long long)n_hits, lane);
     wave_atomic_add(&P.ctr->step_limit_hits, limit_hits, lane);

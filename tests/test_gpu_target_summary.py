@@ -32,8 +32,12 @@ def target_words(cfg, net):
             code_to_words(cfg['target substate code'], net.n_words))
 
 
+@pytest.mark.parametrize('cubes', ['0', '1'])
 @pytest.mark.parametrize('case', load('target.json'), ids=lambda c: c['name'])
-def test_summary_equals_the_hit_list(eng, case):
+def test_summary_equals_the_hit_list(eng, case, cubes, monkeypatch):
+    """cubes = 1 (default): aligned blocks of >= 2^16 problems are counted through cube passes (classes of problems
+    that share s(1), s(2), ...); the step statistic then counts a class's steps once per member."""
+    monkeypatch.setenv('BSX_CUBES', cubes)
     cfg, net, space = compile_case(case)
     eng.set_problem(net, space)
     mask, code = target_words(cfg, net)
@@ -47,7 +51,8 @@ def test_summary_equals_the_hit_list(eng, case):
         expect = np.bincount(np.minimum(hits['t'], bins - 1).astype(np.int64), minlength=bins)
         assert hist.tolist() == expect.tolist()
         assert first.tobytes() == hits[:cap].tobytes()
-        assert st2['state_steps'] == st['state_steps']
+        if cubes == '0':
+            assert st2['state_steps'] == st['state_steps']
     # a sub-range that starts inside the space (offsets are relative to `first`)
     lo = n // 3
     part, _ = eng.target(lo, n - lo, max_t, mask, code)
@@ -73,12 +78,13 @@ def test_config4_full_size(eng):
     # the listed hits are the first ones in index order
     lst, _ = eng.target(0, 1 << 12, 1024, mask, code)
     assert first[:len(lst)].tobytes() == lst[:1000].tobytes()
-    # oracle on slices of every variant (and one across a variant boundary)
+    # oracle on slices of every variant (and one across a variant boundary); the last two are aligned blocks
+    # of 2^20 problems, i.e. cube passes
     orc = Oracle(net, space)
     rng = random.Random(4)
-    starts = [(v << 28) + rng.randrange((1 << 28) - (1 << 16)) for v in range(8)] + [(3 << 28) - 30000]
-    for s in starts:
-        cnt = 1 << 16
+    starts = [((v << 28) + rng.randrange((1 << 28) - (1 << 16)), 1 << 16) for v in range(8)] + [((3 << 28) - 30000, 1 << 16)]
+    starts += [((5 << 28) + (37 << 20), 1 << 20), ((2 << 28) + (200 << 20) + (1 << 19), 1 << 20)]
+    for s, cnt in starts:
         got, h, _, _ = eng.target_summary(s, cnt, 1024, mask, code, hist_bins=1026)
         pp, _ = orc.target(s, cnt, 1024, mask, code, n_threads=CORES)
         reached = pp['reached'] != 0
