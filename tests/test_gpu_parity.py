@@ -151,20 +151,23 @@ def _same_attract(eng, orc, first, count, max_t, max_len=None):
     return r
 
 
-@pytest.mark.parametrize('name,text,space_bits', [
-    ('northstar_n64', synth.north_star_yaml(), 64),
-    ('config3_n32', synth.config3_yaml(), 32),
-    ('cambium2', open(os.path.join(GOLDEN, 'cambium2.yaml')).read(), 30),
-    ('synth_n128', synth.network_yaml(128, 2, 129), 128),
-    ('synth_n256_k3', synth.network_yaml(256, 3, 256), 256),
-    ('synth_n48_k6', synth.network_yaml(48, 6, 48), 48),
-], ids=lambda v: v if isinstance(v, str) and len(v) < 30 else None)
-def test_attract_vs_oracle_slices(eng, name, text, space_bits):
+SLICE_CASES = [
+    ('northstar_n64', synth.north_star_yaml(), 64, 14),
+    ('config3_n32', synth.config3_yaml(), 32, 14),
+    ('cambium2', open(os.path.join(GOLDEN, 'cambium2.yaml')).read(), 30, 14),
+    ('synth_n128', synth.network_yaml(128, 2, 129), 128, 14),
+    ('synth_n256_k3', synth.network_yaml(256, 3, 256), 256, 12),      # (chaotic: transients of thousands of steps)
+    ('synth_n48_k6', synth.network_yaml(48, 6, 48), 48, 13),
+]
+
+
+@pytest.mark.parametrize('name,text,space_bits,log2n', SLICE_CASES, ids=[c[0] for c in SLICE_CASES])
+def test_attract_vs_oracle_slices(eng, name, text, space_bits, log2n):
     cfg, net, space, orc = _setup(eng, text, Mode.ATTRACT, 4096)
-    rng = random.Random(hash(name) & 0xFFFF)
-    _same_attract(eng, orc, 0, 1 << 14, 4096)
+    rng = random.Random(sum(map(ord, name)))
+    _same_attract(eng, orc, 0, 1 << log2n, 4096)
     first = rng.randrange((1 << space_bits) - (1 << 14))
-    _same_attract(eng, orc, first, (1 << 14) + 77, 4096)          # ragged count, unaligned base
+    _same_attract(eng, orc, first, (1 << log2n) + 77, 4096)       # ragged count, unaligned base
     _same_attract(eng, orc, first, 1000, 9, 3)                    # tight caps: many "no attractor"
     _same_attract(eng, orc, first, 1, 4096)                       # single problem
     r = eng.attract(first, 0, 4096)                               # empty range
