@@ -84,7 +84,7 @@ def main():
                 roof = roofline(fg_bytes, st['kernel_ms'], note='array bytes the {} passes stream through HBM ({} doubling + {} jump rounds), '
                                 'a random gather counted at its 4 or 8 useful bytes'.format(st['kernel_launches'], doubling, jumps))
             else:
-                run_attract_range(eng, first, count if count <= 1 << 32 else count >> 4, max_t)     # warm the cycle cache and the scratch buffers
+                run_attract_range(eng, first, count, max_t)     # warms the cycle cache and the scratch buffers
                 t0 = time.perf_counter()
                 merged, none, st = run_attract_range(eng, first, count, max_t)
                 dt = time.perf_counter() - t0
