@@ -6,7 +6,7 @@ Differences, all outside the hot path: results are kept in memory instead of a Z
 (`-d`, `-k` accepted and ignored); `-b` does not schedule anything (the GPU dequeues its own chunks),
 it only shapes the listing order under `--reference-np`; graphic outputs are not produced (`--no-pdf`
 is implied, `--print-*` warn).  Started once per GPU by a launcher that sets RANK / WORLD_SIZE / MASTER_*
-(e.g. `python -m torch.distributed.run`), every rank drives one GPU and all three commands range-partition
+(the elastic launcher the benchmark driver uses does), every rank drives one GPU and all three commands range-partition
 the problems (boolsi_amd/dist.py); rank 0 owns the output directory: it creates it, copies the input there
 and writes the results, and its path is the one every rank uses.
 `--reference-np P` lists the simulations of simulate / target in the order a reference run under

@@ -12,7 +12,7 @@ Two planes:
            128-byte ncclUniqueId from rank 0 to the others, barriers, the record counts that size the
            all-gather, scalar reductions of run statistics, and it is how a rank learns that a peer has
            died (closed socket) instead of blocking in a collective for ever.  Pure Python, no MPI, no
-           torch.  Rendezvous: rank 0 listens on an ephemeral port and publishes it in a file named
+           tensor framework.  Rendezvous: rank 0 listens on an ephemeral port and publishes it in a file named
            after MASTER_PORT and the launcher's pid (the port itself belongs to the launcher's store).
   data     RCCL, once `attach_engine` has built the communicator.  Without an engine the data collectives
            refuse to run unless BSX_DIST_BACKEND=socket explicitly routes them through the control

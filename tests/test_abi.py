@@ -50,6 +50,22 @@ def test_no_gpu_means_loud_failure_not_fallback():
         Engine(0)
 
 
+def test_product_package_uses_no_tensor_framework():
+    """north_star: ctypes + HIP + RCCL only.  Nothing under boolsi_amd/ may import torch (the multi-GPU merge is
+    ncclAllGather behind the C-ABI, the rendezvous a TCP socket)."""
+    import re
+    pkg = os.path.join(ROOT, 'boolsi_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+torch', text, flags=re.M), f
+    import subprocess
+    import sys
+    code = 'import sys; import boolsi_amd.cli, boolsi_amd.dist, boolsi_amd.attract, boolsi_amd.engine; assert "torch" not in sys.modules'
+    assert subprocess.run([sys.executable, '-c', code], cwd=ROOT).returncode == 0
+
+
 def test_product_package_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, 'boolsi_amd')
     for dirpath, _, files in os.walk(pkg):
