@@ -23,8 +23,8 @@ Accounting (what each number counts):
                                         dominant kernel / its HIP-event duration, vs 8 TB/s.  <= 1 by
                                         construction.  The kernel keeps states in registers/LDS, so its real
                                         HBM traffic (`traffic`, from a separate PMC pass) is ~1e-4 of that and
-                                        HBM is not what limits it: `issue_bound` gives the limiter that the PMC
-                                        counters show (VALU issue + LDS), from the profile named in its `source`.
+                                        HBM is not what limits it: `issue_bound` gives what the PMC counters show
+                                        (VALU, SALU and LDS busy fractions), from the profile named in its `source`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch B]
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); this program itself
