@@ -226,3 +226,19 @@ def test_failing_rank_ends_the_job_with_a_nonzero_status(tmp_path):
         procs.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert [p.returncode for p in procs] == [1, 1], outs
+
+
+def test_attract_cambium2_cli_reproduces_the_published_output(tmp_path):
+    """`boolsi attract examples/cambium2.yaml` took the reference 45 h on 63 MPI workers (examples/output8_cambium2/
+    boolsi.log); here the whole command -- 2^30 initial conditions, CSV output -- runs in seconds.  attractors.csv must
+    be byte-identical; the summaries agree to 1e-9 (the reference accumulates mean / M2 in floating point, batch by
+    batch) and in the order of the attractors."""
+    out = run_cli(['attract', os.path.join(GOLDEN, 'cambium2.yaml'), '-c'], str(tmp_path))
+    assert 'Found 39 attractors.' in out
+    assert read(tmp_path / 'attractors.csv') == read(os.path.join(GOLDEN, 'cambium2_attractors.csv'))
+    ours = list(csv.reader(open(tmp_path / 'attractor_summaries.csv')))
+    ref = list(csv.reader(open(os.path.join(GOLDEN, 'cambium2_attractor_summaries.csv'))))
+    assert len(ours) == len(ref) == 40 and ours[0] == ref[0]
+    for a, b in zip(ours[1:], ref[1:]):
+        assert a[:2] == b[:2] and float(a[4]) == float(b[4])
+        assert math.isclose(float(a[2]), float(b[2]), rel_tol=1e-9) and math.isclose(float(a[3]), float(b[3]), rel_tol=1e-7)
