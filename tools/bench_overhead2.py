@@ -1,4 +1,5 @@
-import sys,time; sys.path.insert(0,'/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from boolsi_amd import synth
 from boolsi_amd.compile import compile_problem
 from boolsi_amd.constants import Mode
