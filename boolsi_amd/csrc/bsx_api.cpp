@@ -517,6 +517,8 @@ int mirror_slots_for(bsx_handle h, uint32_t* slots_out) {
 }
 
 int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
+    uint32_t ignored = 0;
+    if (!slots_out) slots_out = &ignored;
     if (!h->journal_stale) return mirror_slots_for(h, slots_out);
     unsigned int known = 0;
     HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
@@ -759,6 +761,44 @@ void advance_first(DevSpace& sp, const bsx_index* first, uint64_t delta) {
 
 }  // namespace
 
+// Spaces with more than 64 'any' nodes (e.g. a 128-node network with every node 'any'): a call covers at most
+// 2^48 consecutive problems, so only the 64 lowest initial-state digits can change inside it.  The call is run as
+// the space in which exactly those are 'any' and the higher digits of `first` are part of the origin state -- a
+// plain space, which gets the lean / pool / cube paths.  (Same network, same fixed nodes: the cycle cache carries over.)
+static int run_attract_low_digits(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t, uint64_t max_len,
+                                  bsx_attr_rec* table, uint32_t cap, uint32_t* n_out, uint64_t* n_no_attractor, bsx_stats* stats) {
+    struct Restore {                    // the handle describes the whole space again, whatever happens below
+        bsx_handle h; DevSpace sp; std::vector<uint32_t> any;
+        ~Restore() { h->sp = sp; h->h_any = any; h->in_low_digit_call = false; }
+    } restore{h, h->sp, h->h_any};
+    h->in_low_digit_call = true;
+    DevSpace sv = h->sp;
+    bool identity = true;
+    for (uint32_t j = 0; j < 64; ++j) identity = identity && h->h_any[j] == j;
+    for (uint32_t j = 64; j < h->sp.n_any; ++j)
+        if ((first->init_digits[j >> 6] >> (j & 63)) & 1ull) sv.origin[h->h_any[j] >> 5] |= 1u << (h->h_any[j] & 31);
+    sv.n_any = 64;
+    sv.identity_any = identity ? 1 : 0;
+    sv.n_runs = 0;
+    if (!identity) {
+        uint32_t j = 0, r = 0;
+        while (j < 64) {
+            uint32_t len = 1;
+            while (j + len < 64 && h->h_any[j + len] == h->h_any[j] + len && ((h->h_any[j] + len) >> 5) == (h->h_any[j] >> 5)) ++len;
+            sv.deposit[2 * r] = j | (h->h_any[j] >> 5) << 8 | (h->h_any[j] & 31u) << 16;
+            sv.deposit[2 * r + 1] = len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u;
+            ++r;
+            j += len;
+        }
+        sv.n_runs = r;                  // <= 64 = kMaxDepositRuns
+    }
+    h->sp = sv;
+    h->h_any.resize(64);
+    bsx_index f{};
+    f.init_digits[0] = first->init_digits[0];
+    return bsx_run_attract(h, &f, count, max_t, max_len, table, cap, n_out, n_no_attractor, nullptr, stats);
+}
+
 extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
                                uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
                                uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats) {
@@ -776,6 +816,14 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // 2^48: sum_l (64 bits) holds count x trajectory length; ranges above 2^32 must collapse into cubes (below)
     if (count > (1ull << 48)) return fail(h, BSX_ERR_INVALID, "at most 2^48 problems per call");
     if (per_problem && count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call with per-problem records");
+
+    if (h->sp.n_any > 64 && !h->sp.n_fv && !h->sp.n_pv && h->sp.tp_origin <= 200 && !per_problem && !h->in_low_digit_call &&
+        count >= (1u << 13) && h->cache_enabled && first->init_digits[0] + (count - 1) >= first->init_digits[0] &&
+        !(std::getenv("BSX_LEAN") && std::atoi(std::getenv("BSX_LEAN")) == 0)) {
+        const int rc = run_attract_low_digits(h, first, count, max_t, max_len, table, cap, n_out, n_no_attractor, stats);
+        if (stats) stats->total_ms = now_ms() - t_begin;
+        return rc;
+    }
 
     DevBuf<LogRec>& d_log = h->d_log;
     DevBuf<ProblemRec32> d_pp;
@@ -871,6 +919,8 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     auto run_tiles = [&](uint64_t seg_end) -> int {
     while (use_fast && h->fast_ok && done < seg_end) {
         const uint64_t tile = std::min<uint64_t>(seg_end - done, h->fast_calibrated ? kLeanTile : kProbeTile);
+        if (int rc = lean_mirror_slots(h, nullptr)) return rc;          // (refreshes h->h_journal if the detector ran since)
+        const unsigned int known_before_tile = (unsigned int)h->h_journal.size();
         // straggler list: one word per problem, or up to three per class (base + 64-bit member mask) from the
         // pool kernel -- probe tiles get room for every problem as a class of its own, big tiles for a third
         // (more stragglers than that and the lean path is the wrong tool anyway)
@@ -944,7 +994,14 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
             h->fast_steps = std::min(kFastStepsMax, h->fast_steps * 4);     // long transients: give FAST more steps
         } else {
             if (tile >= kFastMinProblems) h->fast_calibrated = true;
-            if (r.ctr.n_stragglers > tile / 2) h->fast_ok = false;          // the cache does not cover this space
+            if (r.ctr.n_stragglers > tile / 2) {
+                // Most of the tile went to the detector.  If that taught the cache new attractors (a region of the
+                // space nobody had visited), the next tile will do better; if not -- cycles too long to cache,
+                // or more attractors than the mirror holds -- the lean path is the wrong tool for this space.
+                unsigned int known_now = 0;
+                HIPCHK(h, hipMemcpy(&known_now, h->d_cc_count.p, sizeof(known_now), hipMemcpyDeviceToHost));
+                if (known_now <= known_before_tile) h->fast_ok = false;
+            }
         }
     }
     if (done < seg_end) {           // not (or no longer) a case for the lean path: the detector takes the rest

@@ -85,6 +85,7 @@ struct bsx_engine {
     std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
     std::vector<uint32_t> h_any;        // 'any' nodes in digit order (cube collapse: relevant-digit analysis)
     std::vector<uint32_t> h_fv;         // fixed-node variations (node, range) in digit order
+    bool in_low_digit_call = false;     // bsx_run_attract is running a > 64-digit space as its 64 lowest digits
 
     // problem space
     bool have_space = false;

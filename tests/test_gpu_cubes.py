@@ -81,6 +81,18 @@ def test_cubes_vs_oracle_other_networks(eng, name, text, bits, log2n):
     same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << (log2n - 1)) + 99)
 
 
+def test_spaces_with_more_than_64_any_nodes_run_as_their_low_digits(eng):
+    """n = 128 / 200, every node 'any': a call can only change the 64 lowest digits, so it runs as that plain
+    space (higher digits of `first` folded into the origin) and gets the lean / pool / cube paths."""
+    for n, seed in ((128, 129), (200, 2001)):
+        net, space = setup(eng, synth.network_yaml(n, 2, seed))
+        for first, count in (((0x9E3779B97F4A7C15 << 60) | (1 << 22), 1 << 22), ((1 << (n - 1)) + (5 << 64) + 12345, (1 << 21) + 99)):
+            same_as_oracle(eng, net, space, first, count)
+            if n == 128:
+                again = eng.attract(first, count, 4096)     # attractors of this region cached now: pool / cube passes only
+                assert again.stats['executed_steps'] < count
+
+
 def test_first_contact_with_an_attractor_in_a_cube_pass(eng):
     """Fresh engine, nothing cached beyond what the discovery sample finds: whatever attractor shows up first
     inside a cube pass must be learnt (detector from the listed class states) and the pass repeated."""
