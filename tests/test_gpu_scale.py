@@ -86,3 +86,31 @@ def test_config3_full_sweep_conservation_and_partition(eng):
     got = eng.attract(first, count, 4096)
     _, table, none, steps = Oracle(net, space).attract(first, count, 4096, per_problem=False, n_threads=CORES)
     assert rows(got.table) == rows(table) and got.n_no_attractor == none and got.stats['state_steps'] == steps
+
+
+def test_config5_full_size_with_digests(eng):
+    """BASELINE config 5 at its full size: n = 128, K = 3, perturbation schedule, simulate -t 10000 over all 2^26
+    problems, fold digests from the bit-sliced kernel (2^22 problems per call).  Oracle on two slices of 2^10,
+    and partition invariance: a window that straddles the call boundaries gives the digests the whole run gave."""
+    from oracle.cpu_oracle import Oracle
+    cfg = parse_input_text(synth.config5_yaml(), 10000, Mode.SIMULATE)
+    net, space = compile_problem(cfg)
+    eng.set_problem(net, space)
+    n = space.n_problems
+    assert n == 1 << 26
+    digests = np.zeros(n, np.uint64)
+    steps = 0
+    for first in range(0, n, 1 << 22):
+        _, _, dig, st = eng.simulate(first, 1 << 22, 10000, trajectories=False, final=False, digest=True)
+        digests[first:first + (1 << 22)] = dig
+        steps += st['state_steps']
+    assert steps == n * 10000
+    orc = Oracle(net, space)
+    for first in (0, (37 << 20) + 12345):
+        _, _, odig, _ = orc.simulate(first, 1 << 10, 10000, want_traj=False, n_threads=CORES)
+        assert np.array_equal(digests[first:first + (1 << 10)], odig)
+    first = (3 << 22) - (1 << 19) + 777                      # straddles a call boundary, unaligned
+    _, fin, dig, _ = eng.simulate(first, 1 << 20, 10000, trajectories=False, final=True, digest=True)
+    assert np.array_equal(dig, digests[first:first + (1 << 20)])
+    _, ofin, _, _ = orc.simulate(first, 1 << 9, 10000, want_traj=False, n_threads=CORES)
+    assert np.array_equal(fin[:1 << 9], ofin)
