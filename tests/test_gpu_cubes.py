@@ -154,3 +154,40 @@ def test_large_ranges_cubes_equal_plain_enumeration_and_partition(eng):
     quarters = [eng.attract(base + q * (n // 4), n // 4, 4096) for q in range(4)]
     assert merged_rows([big.table]) == merged_rows([q.table for q in quarters])
     assert big.stats['state_steps'] == sum(q.stats['state_steps'] for q in quarters)
+
+
+@pytest.mark.parametrize('seed', range(96))
+def test_cubes_equal_plain_enumeration_on_random_spaces(eng, seed):
+    """Differential fuzz: random small networks (fixed nodes, warm-ups under perturbations, tight caps, ragged
+    ranges) through the cube passes and through the plain enumeration -- tables, no-attractor counts and
+    reference step counts must be identical.  (The plain path is pinned against the oracle elsewhere.)"""
+    import random
+    rng = random.Random(1000 + seed)
+    n = rng.choice((18, 20, 22))
+    k = rng.choice((1, 2, 2, 3))
+    fixed = {rng.randrange(n): rng.choice('01')} if rng.random() < 0.4 else None
+    pert = None
+    if rng.random() < 0.4:
+        pert = {rng.randrange(n): {rng.choice('01'): ', '.join(str(t) for t in sorted(rng.sample(range(1, 7), rng.randrange(1, 4))))}}
+    initial = None
+    if rng.random() < 0.3:          # some nodes not 'any': the digits are deposited run by run
+        initial = {i: rng.choice('01') for i in rng.sample(range(n), 2)}
+    max_t = rng.choice((np.inf, 4096, 4096, 9, 7))
+    max_len = rng.choice((np.inf, np.inf, 1, 2))
+    text = synth.network_yaml(n, k, 5000 + seed, initial=initial, fixed=fixed, perturbations=pert)
+    net, space = setup(eng, text, max_t)
+    total = space.n_problems
+    count = rng.randrange(min(1 << 17, total // 2), total + 1)
+    first = rng.randrange(0, total - count + 1)
+    if rng.random() < 0.5:
+        first &= ~0xFFFF
+    os.environ.pop('BSX_CUBES', None)
+    a = eng.attract(first, count, max_t, max_len)
+    os.environ['BSX_CUBES'] = '0'
+    try:
+        b = eng.attract(first, count, max_t, max_len)
+    finally:
+        os.environ.pop('BSX_CUBES')
+    assert rows(a.table) == rows(b.table), text
+    assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
+    assert int(a.table['count'].sum()) + a.n_no_attractor == count

@@ -90,3 +90,36 @@ def test_config4_full_size(eng):
         reached = pp['reached'] != 0
         assert got == int(reached.sum())
         assert h.tolist() == np.bincount(pp['t_stop'][reached].astype(np.int64), minlength=1026).tolist()
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_target_cube_passes_equal_plain_counting_on_random_spaces(eng, seed, monkeypatch):
+    """Differential fuzz of the summary sink: random networks, targets, caps and fixed-node variations; cube
+    passes (default) against plain counting (BSX_CUBES=0): hit counts and histograms must be identical."""
+    rng = random.Random(7000 + seed)
+    n = rng.choice((18, 20, 22))
+    k = rng.choice((1, 2, 2, 3))
+    n_const = rng.choice((0, 0, 2))
+    initial = {i: rng.choice('01') for i in rng.sample(range(n), n_const)} or None
+    fixed = None
+    if rng.random() < 0.6:
+        fixed = {i: rng.choice(('0', '1', '0?', '1?', 'any', 'any?')) for i in rng.sample(range(n), rng.randrange(1, 3))}
+    tnodes = rng.sample(range(n), rng.randrange(1, 6))
+    target = {i: (rng.choice('01') if i in tnodes else 'any') for i in range(n)}
+    max_t = rng.choice((np.inf, 1024, 6, 2))
+    text = synth.network_yaml(n, k, 9000 + seed, initial=initial, fixed=fixed, target=target)
+    cfg = parse_input_text(text, max_t, Mode.TARGET)
+    net, space = compile_problem(cfg)
+    eng.set_problem(net, space)
+    mask, code = target_words(cfg, net)
+    total = space.n_problems
+    count = rng.randrange(min(1 << 17, total // 2), total + 1)
+    first = rng.randrange(0, total - count + 1)
+    if rng.random() < 0.5:
+        first &= ~0xFFFF
+    cap = rng.choice((0, 0, 5))
+    monkeypatch.setenv('BSX_CUBES', '1')
+    a = eng.target_summary(first, count, max_t, mask, code, hist_bins=64, cap=cap)
+    monkeypatch.setenv('BSX_CUBES', '0')
+    b = eng.target_summary(first, count, max_t, mask, code, hist_bins=64, cap=cap)
+    assert a[0] == b[0] and a[1].tolist() == b[1].tolist() and a[2].tobytes() == b[2].tobytes(), text
