@@ -813,6 +813,11 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     if (n_no_attractor) *n_no_attractor = 0;
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (count == 0) return BSX_OK;
+    if (const char* fg = std::getenv("BSX_FGRAPH")) {           // knob: route eligible calls through the functional-graph mode
+        if (fg[0] == '1' && !per_problem && h->n_nodes <= 32 && h->sp.n_any == h->n_nodes && h->sp.identity_any && !h->sp.n_fv &&
+            !h->sp.n_pv && h->lut_mode != 2)
+            return bsx_run_attract_fgraph(h, first, count, max_t, max_len, table, cap, n_out, n_no_attractor, stats);
+    }
     // 2^48: sum_l (64 bits) holds count x trajectory length; ranges above 2^32 must collapse into cubes (below)
     if (count > (1ull << 48)) return fail(h, BSX_ERR_INVALID, "at most 2^48 problems per call");
     if (per_problem && count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call with per-problem records");

@@ -228,7 +228,13 @@ def test_failing_rank_ends_the_job_with_a_nonzero_status(tmp_path):
     assert [p.returncode for p in procs] == [1, 1], outs
 
 
-def test_attract_cambium2_cli_reproduces_the_published_output(tmp_path):
+@pytest.mark.parametrize('fgraph', ['0', '1'])
+def test_attract_cambium2_cli_reproduces_the_published_output(tmp_path, fgraph, monkeypatch):
+    monkeypatch.setenv('BSX_FGRAPH', fgraph)       # 1: the same command through the functional-graph mode
+    _cambium2_cli(tmp_path)
+
+
+def _cambium2_cli(tmp_path):
     """`boolsi attract examples/cambium2.yaml` took the reference 45 h on 63 MPI workers (examples/output8_cambium2/
     boolsi.log); here the whole command -- 2^30 initial conditions, CSV output -- runs in seconds.  attractors.csv must
     be byte-identical; the summaries agree to 1e-9 (the reference accumulates mean / M2 in floating point, batch by
