@@ -376,8 +376,16 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         //      after the resolve block, whose arithmetic hides the two LDS round trips
         bool cand = live && res == 0 && t < fast_steps;
         // (sibling states differ in a few bits: the slot needs a mixing hash; 24-bit multiplies are full rate)
-        const uint32_t hx = hfull ^ (hfull >> 15) ^ (counting ? (uint32_t)t : base >> 6);
-        const uint32_t slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kPoolSlots - 1);
+        uint32_t slot;
+        if constexpr (cube) {
+            // hash_state has folded the upper half of the hash into its low 16 bits, so one 24-bit multiply mixes
+            // all of it: five instructions fewer than the two-multiply mix below and, on cube passes, 3 % fewer
+            // updates (on plain tiles it was 2 % more, so they keep theirs)
+            slot = (__umul24(hfull ^ (uint32_t)t, 0x9E3779u) >> 17) & (kPoolSlots - 1);
+        } else {
+            const uint32_t hx = hfull ^ (hfull >> 15) ^ (counting ? (uint32_t)t : base >> 6);
+            slot = ((__umul24(hx, 0x9E3779u) ^ __umul24(hx >> 11, 0x85EBCBu)) >> 12) & (kPoolSlots - 1);
+        }
         if (cand) dd_ids[slot] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
