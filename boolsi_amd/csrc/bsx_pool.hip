@@ -435,8 +435,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         {
             // every lane takes part in the permutes (a lane masked off would deliver nothing to its readers)
             uint32_t differ = counting ? 0u : (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)base) ^ base;
-            differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)(cand ? 0u : 1u));
-            differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), t) ^ (uint32_t)t;      // (same group = same time in a FIFO pool; checked anyway)
+            // the slot's owner must be a candidate itself and at the same time: one permute for both
+            const uint32_t tc = ((uint32_t)t << 1) | (cand ? 0u : 1u);
+            differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)tc) ^ ((uint32_t)t << 1);
 #pragma unroll
             for (int i = 0; i < NW; ++i) differ |= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w * 4u), (int)A[i]) ^ A[i];
             const bool same = cand & (w != lane) & (differ == 0u);
