@@ -83,7 +83,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     const uint32_t cmask = P.cc.lds_slots - 1;
     constexpr int S = CacheLayout<NW>::kStride;
     constexpr uint32_t kAccs = (uint32_t)kTagAcc + kLdsAcc;
-    constexpr uint32_t R = pool_rec_words(NW);
+    // ring record: state, group base, members lo/hi, time.  A cube pass has no group base and packs the time next to
+    // the high word of its member count (count < 2^49, -256 <= t < 2^12 - 256): NW + 2 words -- one 16-byte access
+    // at NW = 2 -- and what the shorter records free goes into a longer ring.
+    constexpr uint32_t R = cube ? NW + 2 : pool_rec_words(NW);
+    constexpr uint32_t kCap = cube ? (kPoolCap * pool_rec_words(NW)) / (NW + 2) : kPoolCap;
 
     // LDS: [network tables][cache mirror][per attractor: sum l^2, sum l (u64), count, length (u32), key]
     //      [per wave: pool records | 64 x 8 B member accumulators | 256 one-byte lane ids]
@@ -95,14 +99,14 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     unsigned long long* acc_cnt = acc_sl + kAccs;
     uint32_t* lamtab = reinterpret_cast<uint32_t*>(acc_cnt + kAccs);
     uint32_t* keytab = lamtab + kAccs;
-    constexpr uint32_t kWaveWords = kPoolCap * R + 128 + kPoolSlots / 4;
+    constexpr uint32_t kWaveWords = kPoolCap * pool_rec_words(NW) + 128 + kPoolSlots / 4;
     static_assert(kAccs % 2 == 0 && kWaveWords % 2 == 0, "64-bit LDS atomics need 8-byte aligned tables");
     uint32_t* midtab = keytab + ((kAccs * NW + 1u) & ~1u);      // cube pass: deposits of class-index bits 6..11, [64][NW]
     uint32_t* wave_base = midtab + 64 * NW + wave * kWaveWords;
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
     lds_vu32* const pool = (lds_vu32*)(__attribute__((address_space(3))) uint32_t*)wave_base;
-    lds_vu32* const dd_acc = pool + kPoolCap * R;           // [64][2]
+    lds_vu32* const dd_acc = pool + kPoolCap * pool_rec_words(NW);           // [64][2]
     lds_vu8* const dd_ids = (lds_vu8*)(dd_acc + 128);
 
     uint32_t fm0[NW], fv0[NW];
@@ -268,14 +272,27 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         uint32_t A[NW], base = 0, mlo = 0, mhi = 0, res = 0, hfull = 0;
         int32_t t = 0;
         bool live = false;
-        if (count > kPoolCap - kPoolGroup || !input) {
+        if (count > kCap - kPoolGroup || !input) {
             // ---- pool stage: the oldest classes (their states were looked up when they were stored)
             const uint32_t n = count < 64u ? count : 64u;
             live = lane < n;
             uint32_t ri = head + lane;
-            ri -= ri >= kPoolCap ? kPoolCap : 0u;
+            ri -= ri >= kCap ? kCap : 0u;
             const uint32_t r = ri * R;
-            if constexpr (NW % 2 == 0) {        // 8-byte accesses (records are 8-byte aligned for even NW)
+            if constexpr (cube) {
+                uint32_t packed;
+                if constexpr (NW == 2) {
+                    typedef volatile bsx_u32x4 __attribute__((address_space(3))) lds_v4;
+                    const bsx_u32x4 v = *(lds_v4*)(pool + r);
+                    A[0] = live ? v.x : 0u; A[1] = live ? v.y : 0u; mlo = v.z; packed = v.w;
+                } else {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) A[w] = live ? pool[r + w] : 0u;
+                    mlo = pool[r + NW]; packed = pool[r + NW + 1];
+                }
+                mhi = packed & 0x1FFFFu;
+                t = (int32_t)(packed >> 17) - 256;
+            } else if constexpr (NW % 2 == 0) {        // 8-byte accesses (records are 8-byte aligned for even NW)
                 typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
                 lds_v2* rec = (lds_v2*)(pool + r);
 #pragma unroll
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 base = pool[r + NW]; mlo = pool[r + NW + 1]; mhi = pool[r + NW + 2]; t = (int32_t)pool[r + NW + 3];
             }
             head += n;
-            head -= head >= kPoolCap ? kPoolCap : 0u;
+            head -= head >= kCap ? kCap : 0u;
             count -= n;
 #ifdef BSX_DIAG
             dbg_is_fresh = false;
@@ -460,7 +477,12 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (cand) {
-                    const uint32_t glo = dd_acc[2 * lane], ghi = dd_acc[2 * lane + 1];
+                    uint32_t glo, ghi;
+                    if constexpr (cube) {
+                        typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
+                        const bsx_u32x2 gv = *(lds_v2*)(dd_acc + 2 * lane);
+                        glo = gv.x; ghi = gv.y;
+                    } else { glo = dd_acc[2 * lane]; ghi = dd_acc[2 * lane + 1]; }
                     if (glo | ghi) {
                         if constexpr (cube) {
                             const unsigned long long sum = (((unsigned long long)mhi << 32) | mlo) + (((unsigned long long)ghi << 32) | glo);
@@ -481,11 +503,23 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         if (cand) {
             const uint32_t rank = __popcll(keepers & ((1ull << lane) - 1ull));
             uint32_t tail = head + count;                   // uniform; head < cap, count <= cap
-            tail -= tail >= kPoolCap ? kPoolCap : 0u;
+            tail -= tail >= kCap ? kCap : 0u;
             uint32_t ri = tail + rank;
-            ri -= ri >= kPoolCap ? kPoolCap : 0u;
+            ri -= ri >= kCap ? kCap : 0u;
             const uint32_t r = ri * R;
-            if constexpr (NW % 2 == 0) {
+            if constexpr (cube) {
+                const uint32_t packed = mhi | ((uint32_t)(t + 256) << 17);
+                if constexpr (NW == 2) {
+                    typedef volatile bsx_u32x4 __attribute__((address_space(3))) lds_v4;
+                    bsx_u32x4 v;
+                    v.x = A[0]; v.y = A[1]; v.z = mlo; v.w = packed;
+                    *(lds_v4*)(pool + r) = v;
+                } else {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) pool[r + w] = A[w];
+                    pool[r + NW] = mlo; pool[r + NW + 1] = packed;
+                }
+            } else if constexpr (NW % 2 == 0) {
                 typedef volatile bsx_u32x2 __attribute__((address_space(3))) lds_v2;
                 lds_v2* rec = (lds_v2*)(pool + r);
 #pragma unroll
