@@ -350,6 +350,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_claims.p, 0, sizeof(unsigned int) * kCycleClaimSlots));
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     h->fast_ok = true;
+    h->cube_depth_cap = 0;
     h->h_journal.clear();
     h->journal_stale = true;
     h->fast_steps = 0;
@@ -706,6 +707,58 @@ void plan_cube(const bsx_engine* h, Cube& c) {
     c.sp = sp;
 }
 
+// Deeper collapse: the digits of the block that F^d(x) still depends on, d = 1 .. max_depth, as masks over the
+// digit index (out[d - 1]; a <= 48).  Constant propagation over the block: a node's value after s updates is
+// 0, 1 or "varies" with the set of free digits it may depend on; a rule is restricted to the inputs that are
+// constant over the block and counts a varying input only if the restricted truth table is sensitive to it.
+// An over-approximation (never misses a dependence), and out[0] is build_cube's set.  out[d] is a subset of
+// out[d - 1]: the members of a depth-d class share F^d(x) and everything after it.
+void cube_levels(const bsx_engine* h, const Cube& c, uint32_t max_depth, std::vector<uint64_t>& out) {
+    const uint32_t n = h->n_nodes;
+    const uint32_t* fixmask = h->sp.fixmask;
+    std::vector<uint8_t> val(n), nval(n);       // 0 / 1 / 2 = varies
+    std::vector<uint64_t> dep(n, 0), ndep(n, 0);
+    for (uint32_t i = 0; i < n; ++i) val[i] = (c.base[i >> 5] >> (i & 31)) & 1u;
+    for (uint32_t j = 0; j < c.a; ++j) { const uint32_t node = h->h_any[j]; val[node] = 2; dep[node] = 1ull << j; }
+    out.clear();
+    for (uint32_t d = 1; d <= max_depth; ++d) {
+        uint64_t all = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            ndep[i] = 0;
+            if ((fixmask[i >> 5] >> (i & 31)) & 1u) { nval[i] = (h->sp.fixval[i >> 5] >> (i & 31)) & 1u; continue; }
+            const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
+            const uint32_t* preds = h->h_pred_idx.data() + h->h_pred_offsets[i];
+            if (k > (uint32_t)kMaxMuxK) {                // wide rule: varies with whatever its inputs vary with (conservative)
+                nval[i] = 2;
+                for (uint32_t j = 0; j < k; ++j) ndep[i] |= dep[preds[j]];
+                all |= ndep[i];
+                continue;
+            }
+            const uint64_t tt = h->h_tt0[i];
+            uint32_t var_slots = 0, fixed_idx = 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                if (val[preds[j]] == 2) var_slots |= 1u << j;
+                else if (val[preds[j]]) fixed_idx |= 1u << j;
+            }
+            uint32_t seen = 0, sens = 0, x = 0;
+            do {                                        // all assignments of the varying inputs
+                const uint32_t idx = fixed_idx | x;
+                seen |= 1u << ((tt >> idx) & 1ull);
+                for (uint32_t j = 0; j < k; ++j)
+                    if (((var_slots >> j) & 1u) && (((tt >> idx) ^ (tt >> (idx ^ (1u << j)))) & 1ull)) sens |= 1u << j;
+                x = (x - var_slots) & var_slots;
+            } while (x);
+            if (seen != 3u) { nval[i] = seen >> 1; continue; }
+            nval[i] = 2;
+            for (uint32_t j = 0; j < k; ++j) if ((sens >> j) & 1u) ndep[i] |= dep[preds[j]];
+            all |= ndep[i];
+        }
+        out.push_back(all);
+        val.swap(nval);
+        dep.swap(ndep);
+    }
+}
+
 // Relevant digits whose influence dies out first become the lowest class-index bits (k_digit_lifetimes):
 // the classes that merge after a step or two then sit in the same batch.  A heuristic for speed only.
 int order_cube_digits(bsx_handle h, Cube& c) {
@@ -1030,44 +1083,96 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
     // (a warm-up under origin perturbations is fine: the first update still depends on the relevant digits only)
     const bool cubes_ok = use_fast && merge_mode == 2 && !per_problem &&
                           !(cubes_env && cubes_env[0] == '0') && h->sp.n_any >= kCubeMinBits;
-    auto run_cube = [&](const Cube& c, bool& collapsed) -> int {
+    auto run_cube = [&](const Cube& c1, bool& collapsed) -> int {
         collapsed = false;
         const uint32_t nw = h->net.nw, rec_words = nw + 3;
-        const uint32_t r_bits = (uint32_t)c.rel.size();
         const uint64_t tp = h->sp.tp_origin;            // the search starts at s(T_p); class times count from there
         const uint64_t cap_rel = max_t == BSX_T_INF ? BSX_T_INF : max_t - tp;
         const uint32_t cap_rel32 = (cap_rel == BSX_T_INF || cap_rel >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)cap_rel;
         const uint64_t list_cap = 1ull << 20;                   // unresolved classes per pass
+        uint64_t near_cap = 1ull << 22;                         // classes a deep pass may hand to the level below
+        if (const char* e = std::getenv("BSX_CUBE_NEAR_CAP")) near_cap = (uint64_t)std::max(1, std::atoi(e));     // (tests: force the shallower restart)
         if (h->d_strag.n < list_cap * rec_words) HIPCHK(h, h->d_strag.alloc(list_cap * rec_words));
-        for (int attempt = 0; attempt < 16; ++attempt) {
+        const uint32_t fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
+
+        // ---- levels: rel_mask[d - 1] = digits F^d depends on.  The top level is the shallowest one with the
+        // fewest digits (a deeper one would only add updates); BSX_CUBE_DEPTH caps it (1 = first update only).
+        uint32_t max_depth = 8;
+        if (const char* e = std::getenv("BSX_CUBE_DEPTH")) max_depth = (uint32_t)std::max(1, std::min(16, std::atoi(e)));
+        if (h->cube_depth_cap) max_depth = std::min(max_depth, h->cube_depth_cap);
+        if (tp) max_depth = 1;                                  // (with a warm-up the members part ways after s(T_p) only: one level)
+        max_depth = std::max(1u, std::min(max_depth, fast_steps > 1 ? fast_steps - 1 : 1u));
+        std::vector<uint64_t> rel_mask;
+        cube_levels(h, c1, max_depth, rel_mask);
+        uint32_t top = 1;
+        for (uint32_t d = 2; d <= max_depth; ++d)
+            if (__builtin_popcountll(rel_mask[d - 1]) < __builtin_popcountll(rel_mask[top - 1])) top = d;
+        auto level_cube = [&](uint64_t digits, bool ordered, Cube& lc) -> int {
+            lc = c1;
+            lc.rel.clear();
+            for (uint32_t j = 0; j < c1.a; ++j) if ((digits >> j) & 1ull) lc.rel.push_back(j);
+            if (ordered) if (int rc = order_cube_digits(h, lc)) return rc;
+            plan_cube(h, lc);
+            return BSX_OK;
+        };
+
+        for (int attempt = 0; attempt < 32; ++attempt) {
             // every cached attractor must be in the mirror, or a class could sit on a cycle nobody recognises
             uint32_t slots = 0;
             if (int rc = lean_mirror_slots(h, &slots)) return rc;
             uint64_t states = 0;
             for (const CycleRecord& jr : h->h_journal) states += jr.length;
             if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 4 * states > h->cache_lds_slots) return BSX_OK;
-            AttractParams Q = P;
-            Q.sp = c.sp;
-            Q.count = 1ull << r_bits;
-            Q.merge = 3;
-            Q.cube_shift = c.a - r_bits;
-            for (int w = 0; w < kMaxW32; ++w) { Q.cube_umask[w] = c.umask[w]; Q.cube_free[w] = c.free_mask[w]; }
-            Q.fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
-            Q.per_problem = nullptr;
-            Q.stragglers = h->d_strag.p;
-            Q.stragglers_cap = list_cap * rec_words;
-            AttractRun r;
+
             MergedTable pass_table;
-            h->cube_mirror = true;
-            const int rc = launch_attract_pass(h, Q, kPassPool, d_log, &pass_table, r);
-            h->cube_mirror = false;
-            if (rc) return rc;
-            kernel_ms += r.ms; ++launches; steps_exec += r.ctr.steps_exec;
-            if (r.ctr.straggler_overflow) return BSX_OK;                    // too many unresolved classes: not a space for cubes
-            uint64_t extra_none = 0, extra_ref = 0;
-            bool repeat = false;
-            const uint64_t n_unres = r.ctr.straggler_classes;
-            if (n_unres) {
+            uint64_t pass_none = 0, pass_ref = 0;
+            bool repeat = false, lower = false, give_up = false;
+            uint64_t n_entries = 0;
+            for (uint32_t d = top; d >= 1 && !repeat && !lower; --d) {
+                const bool is_top = d == top;
+                if (!is_top && n_entries == 0) break;
+                const uint64_t here = rel_mask[d - 1];
+                const uint32_t r_here = (uint32_t)__builtin_popcountll(here);
+                Cube lc;
+                if (int rc = level_cube(is_top ? here : here & ~rel_mask[d], is_top, lc)) return rc;
+                const uint32_t k_bits = (uint32_t)lc.rel.size();
+                AttractParams Q = P;
+                Q.sp = lc.sp;
+                Q.count = is_top ? 1ull << k_bits : n_entries << k_bits;
+                Q.merge = 3;
+                Q.cube_shift = c1.a - r_here;
+                Q.cube_depth = d;
+                Q.entry_shift = k_bits;
+                Q.entries = is_top ? nullptr : h->d_near[(d + 1) & 1].p;
+                Q.near = nullptr;
+                Q.near_cap = 0;
+                if (d > 1) {
+                    DevBuf<uint32_t>& nb = h->d_near[d & 1];
+                    if (nb.n < near_cap * nw) HIPCHK(h, nb.alloc(near_cap * nw));
+                    Q.near = nb.p;
+                    Q.near_cap = near_cap;
+                }
+                for (int w = 0; w < kMaxW32; ++w) { Q.cube_umask[w] = c1.umask[w]; Q.cube_free[w] = c1.free_mask[w]; }
+                Q.fast_steps = fast_steps;
+                Q.per_problem = nullptr;
+                Q.stragglers = h->d_strag.p;
+                Q.stragglers_cap = list_cap * rec_words;
+                AttractRun r;
+                h->cube_mirror = true;
+                const int rc = launch_attract_pass(h, Q, kPassPool, d_log, &pass_table, r);
+                h->cube_mirror = false;
+                if (rc) return rc;
+                kernel_ms += r.ms; ++launches; steps_exec += r.ctr.steps_exec;
+                if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] cube 2^%u at digit value %llu: depth %u%s, %u digits here (%u relevant), %llu classes, %llu near a cycle, %llu unresolved\n", c1.a, (unsigned long long)c1.d_lo, d, is_top ? " (top)" : "", k_bits, r_here, (unsigned long long)Q.count, (unsigned long long)r.ctr.near_classes, (unsigned long long)r.ctr.straggler_classes);
+                if (r.ctr.straggler_overflow) { give_up = true; break; }    // too many unresolved classes: not a space for cubes
+                if (r.ctr.near_classes > near_cap) { top = d - 1; h->cube_depth_cap = top; lower = true; break; }   // start over, shallower
+                // a level whose classes mostly sit next to a cycle only adds work: later blocks stop above it
+                if (d > 1 && 2 * r.ctr.near_classes > Q.count) h->cube_depth_cap = d - 1;
+                n_entries = r.ctr.near_classes;
+                pass_none += r.ctr.n_none;
+                pass_ref += r.ctr.steps_ref;
+                const uint64_t n_unres = r.ctr.straggler_classes;
+                if (!n_unres) continue;
                 // the detector runs from each listed state: a class that was not on a cycle yet gets its exact
                 // result (all members share the rest of the trajectory); one that sits on a cycle needs that
                 // attractor in the cache -- the detector has just published it -- and the pass is repeated
@@ -1080,7 +1185,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 HIPCHK(h, d_states.upload(st));
                 HIPCHK(h, d_res.alloc(n_unres));
                 AttractParams S = P;
-                S.sp = c.sp;
+                S.sp = lc.sp;
                 S.sp.tp_origin = 0;                     // the listed states are past the warm-up
                 S.count = n_unres;
                 S.states = d_states.p;
@@ -1096,12 +1201,12 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                     const uint32_t* rec = recs.data() + i * rec_words;
                     const uint64_t t_class = rec[nw], m = ((uint64_t)rec[nw + 2] << 32) | rec[nw + 1];
                     const ProblemRec32& pr = res[i];
-                    if (!pr.found) { extra_none += m; extra_ref += m * max_t; continue; }      // (finite cap, or the step limit was hit)
+                    if (!pr.found) { pass_none += m; pass_ref += m * max_t; continue; }        // (finite cap, or the step limit was hit)
                     if (pr.trajectory_l == 0) { repeat = true; break; }                          // on a cycle: members' mu unknown
                     const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length, traj = tp + mu;
                     const bool found = cap_rel == BSX_T_INF || mu + lam <= cap_rel;
-                    extra_ref += found ? m * (traj + lam) : m * max_t;
-                    if (!found || lam > max_len) { extra_none += m; continue; }
+                    pass_ref += found ? m * (traj + lam) : m * max_t;
+                    if (!found || lam > max_len) { pass_none += m; continue; }
                     const Key8 key = key8(pr.key);
                     auto it = pass_table.find(key);
                     if (it == pass_table.end()) {
@@ -1117,17 +1222,18 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                     e.sum_l2_lo = (uint64_t)sq;
                     e.sum_l2_hi += (uint64_t)(sq >> 64);
                 }
-                if (repeat) {
-                    unsigned int known = 0;
-                    HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
-                    if (known <= h->h_journal.size()) return BSX_OK;        // the attractor cannot be cached: no cube for this block
-                    continue;                                               // (the detector pass marked the journal stale)
-                }
+            }
+            if (give_up) return BSX_OK;
+            if (lower) continue;
+            if (repeat) {
+                unsigned int known = 0;
+                HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+                if (known <= h->h_journal.size()) return BSX_OK;        // the attractor cannot be cached: no cube for this block
+                continue;                                               // (the detector pass marked the journal stale)
             }
             fold_table(merged, pass_table);
-            n_none += r.ctr.n_none + extra_none;
-            steps_ref += r.ctr.steps_ref + extra_ref;
-            if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] cube 2^%u at digit value %llu: %u relevant digits, %llu classes unresolved by the pool kernel, pass %d\n", c.a, (unsigned long long)c.d_lo, r_bits, (unsigned long long)n_unres, attempt + 1);
+            n_none += pass_none;
+            steps_ref += pass_ref;
             collapsed = true;
             return BSX_OK;
         }
@@ -1151,8 +1257,6 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 bool collapsed = false;
                 // worth it when the block shrinks at least fourfold (otherwise the tiles do as well and keep member masks)
                 if (c.ok && c.rel.size() + 2 <= a_bits) {
-                    if (int rc = order_cube_digits(h, c)) return rc;
-                    plan_cube(h, c);
                     if (int rc = run_cube(c, collapsed)) return rc;
                 }
                 const uint64_t block_end = (uint64_t)(at - lo) + (1ull << a_bits);      // (a_bits <= 48: fits)

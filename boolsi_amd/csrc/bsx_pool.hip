@@ -167,7 +167,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     }
     __syncthreads();
     // uniform: some member may have mu = 0 (with a warm-up the search starts at s(T_p), which all members share)
-    const bool t0_lookup = cube && !has_warmup && __builtin_amdgcn_readfirstlane(lc[1]) != 0;
+    // (a deep pass hands every class with members that close to a cycle to the level below instead)
+    const uint32_t depth = (cube && P.cube_depth > 1u) ? P.cube_depth : 1u;   // uniform: updates of a fresh class before its first lookup
+    const bool t0_lookup = cube && !has_warmup && depth == 1u && __builtin_amdgcn_readfirstlane(lc[1]) != 0;
     // cube pass: a wave's 64 classes differ in the six lowest relevant digits only; where those land in the
     // state is the same in every iteration, the rest of the class index is wave-uniform (scalar deposit)
     uint32_t lane_part[NW];
@@ -194,6 +196,27 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     unsigned long long dbg_iters = 0, dbg_fresh = 0, dbg_fresh_keep = 0, dbg_pool_in = 0, dbg_pool_keep = 0, dbg_merged = 0;
     bool dbg_is_fresh = false;
 #endif
+
+    // cube pass: the representative state of class `pos + lane`
+    auto fresh_state = [&](uint64_t pos, bool lv, uint32_t (&S0)[NW]) {
+        // (a cube's plan has one run per enumerated digit, so run r is class-index bit r; pos is a multiple of 64)
+        if ((pos >> 12) != u_hi_tag) {                      // uniform, rare
+            u_hi_tag = pos >> 12;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) u_hi[w] = P.sp.origin[w];
+            deposit_runs<NW>(P.sp, pos & ~0xFFFull, u_hi, 12u);
+        }
+        const uint32_t mid = (((uint32_t)pos >> 6) & 63u) * NW;            // uniform: one broadcast read per word
+#pragma unroll
+        for (int w = 0; w < NW; ++w) S0[w] = u_hi[w] | midtab[mid + w] | lane_part[w];
+        if (P.entries) {                                    // uniform: a listed class of the level above, plus this level's digits
+            const uint64_t e = (pos + lane) >> P.entry_shift;
+            if (lv) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) S0[w] |= P.entries[e * NW + w];
+            }
+        }
+    };
 
     // is `s` a cached cycle state?  -> the entry's tag word (0 = no); `hfull` = the state's hash
     uint32_t hit_len = 0;                   // NW <= 2: the entry's length word comes with the probe's 16-byte read
@@ -271,7 +294,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #endif
         uint32_t A[NW], base = 0, mlo = 0, mhi = 0, res = 0, hfull = 0;
         int32_t t = 0;
-        bool live = false;
+        bool live = false, deep_fresh = false;
+        uint64_t fresh_pos = 0;
         if (count > kCap - kPoolGroup || !input) {
             // ---- pool stage: the oldest classes (their states were looked up when they were stored)
             const uint32_t n = count < 64u ? count : 64u;
@@ -323,16 +347,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             live = lane < n;
             base = (uint32_t)q.next;
             if constexpr (cube) {                           // q.next is a multiple of 64 and the class index starts at 0
-                // (a cube's plan has one run per relevant digit, so run r is class-index bit r)
-                if ((q.next >> 12) != u_hi_tag) {           // uniform, rare
-                    u_hi_tag = q.next >> 12;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) u_hi[w] = P.sp.origin[w];
-                    deposit_runs<NW>(P.sp, q.next & ~0xFFFull, u_hi, 12u);
-                }
-                const uint32_t mid = (((uint32_t)q.next >> 6) & 63u) * NW;     // uniform: one broadcast read per word
-#pragma unroll
-                for (int w = 0; w < NW; ++w) A[w] = u_hi[w] | midtab[mid + w] | lane_part[w];
+                fresh_pos = q.next;
+                fresh_state(fresh_pos, live, A);
             } else {
                 init_problem_simple<NW>(P.sp, q.next + lane, A);
             }
@@ -355,6 +371,22 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     const unsigned long long left = (((unsigned long long)mhi << 32) | mlo) - 1ull;
                     mlo = (uint32_t)left; mhi = (uint32_t)(left >> 32);
                     live = left != 0;
+                }
+            }
+            if constexpr (cube) {
+                if (depth > 1u) {
+                    // deep pass: the members of a class share F^depth(x), not the states before it
+                    deep_fresh = true;
+                    if (live) {
+                        for (uint32_t i = 1; i < depth; ++i) {
+                            uint32_t nx[NW];
+                            net_step<NW, K>(nv, A, fm0, fv0, nx, has_fixed);
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) A[w] = nx[w];
+                        }
+                        nexec += depth - 1u;
+                    }
+                    t += (int32_t)(depth - 1u);
                 }
             }
 #ifdef BSX_DIAG
@@ -387,6 +419,26 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
             for (int w = 0; w < NW; ++w) A[w] = nxt[w];
             res = et;
+        }
+        if constexpr (cube) {
+            if (deep_fresh) {
+                // F^depth(x) on a cycle: the members' entry times differ (<= depth) -- list the class for the level below
+                const bool near = live && res != 0;
+                const uint64_t nb = __ballot(near);
+                if (nb) {
+                    uint32_t S0[NW];
+                    fresh_state(fresh_pos, near, S0);
+                    unsigned long long at0 = 0;
+                    if (lane == 0) at0 = atomicAdd(&P.ctr->near_classes, (unsigned long long)__popcll(nb));
+                    const uint32_t at_lo = __builtin_amdgcn_readfirstlane((uint32_t)at0), at_hi = __builtin_amdgcn_readfirstlane((uint32_t)(at0 >> 32));
+                    const unsigned long long at = (((unsigned long long)at_hi << 32) | at_lo) + __popcll(nb & ((1ull << lane) - 1ull));
+                    if (near && at < P.near_cap) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) P.near[at * NW + w] = S0[w];
+                    }
+                }
+                if (near) { live = false; res = 0; }
+            }
         }
 
         // ---- candidates for the merge post their lane id now; the slot is read back right away and used

@@ -25,7 +25,8 @@ def eng():
     e = Engine(0)
     yield e
     e.close()
-    os.environ.pop('BSX_CUBES', None)
+    for k in ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP'):
+        os.environ.pop(k, None)
 
 
 def rows(table):
@@ -188,6 +189,98 @@ def test_cubes_equal_plain_enumeration_on_random_spaces(eng, seed):
         b = eng.attract(first, count, max_t, max_len)
     finally:
         os.environ.pop('BSX_CUBES')
+    assert rows(a.table) == rows(b.table), text
+    assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
+    assert int(a.table['count'].sum()) + a.n_no_attractor == count
+
+
+# ---- deeper collapse: classes by the digits F^d still depends on, near-cycle classes handed down level by level
+
+def shift_register_yaml(n, tail='0'):
+    """x_i <- x_(i+1), the last node constant: every state falls to one fixed point, mu = 1 + its highest set bit.
+    Depth d leaves n - d relevant digits and exactly one class per level sits next to the cycle."""
+    names = ['x{}'.format(i) for i in range(n)]
+    const = '{0} and not {0}' if tail == '0' else '{0} or not {0}'
+    lines = ['nodes:'] + ['    - ' + v for v in names] + ['', 'update rules:']
+    lines += ['    {}: {}'.format(names[i], names[i + 1]) for i in range(n - 1)]
+    lines += ['    {}: {}'.format(names[-1], const.format(names[-1]))]
+    lines += ['', 'initial state:'] + ['    {}: any'.format(v) for v in names]
+    return '\n'.join(lines) + '\n'
+
+
+@pytest.mark.parametrize('depth', [1, 2, 3, 5, 8, 16])
+def test_deep_levels_on_a_shift_register(eng, depth):
+    os.environ['BSX_CUBE_DEPTH'] = str(depth)
+    n = 20
+    net, space = setup(eng, shift_register_yaml(n), np.inf)
+    got = same_as_oracle(eng, net, space, 0, 1 << n, max_t=np.inf)
+    assert len(got.table) == 1 and int(got.table[0]['count']) == 1 << n
+    # mu = 0 once, mu = b + 1 for the 2^b states with highest set bit b
+    assert int(got.table[0]['sum_l']) == sum((b + 1) << b for b in range(n))
+    same_as_oracle(eng, net, space, 3 << 16, 5 << 16, max_t=np.inf)          # blocks that do not hold the fixed point
+    same_as_oracle(eng, net, space, 0, 1 << n, max_t=7)                      # cap inside the levels
+    same_as_oracle(eng, net, space, 0, 1 << n, max_t=np.inf, max_len=0)
+    net, space = setup(eng, shift_register_yaml(n, tail='1'), np.inf)        # the fixed point is all ones: not a representative
+    same_as_oracle(eng, net, space, 0, 1 << n, max_t=np.inf)
+
+
+@pytest.mark.parametrize('depth', [1, 2, 3, 4, 8])
+def test_deep_levels_vs_oracle_on_the_north_star(eng, depth):
+    os.environ['BSX_CUBE_DEPTH'] = str(depth)
+    net, space = setup(eng, synth.north_star_yaml())
+    base = 0x0123456789ABCDEF & ~((1 << 28) - 1)
+    same_as_oracle(eng, net, space, base, 1 << 24)                           # (with the discovery sample)
+    g = same_as_oracle(eng, net, space, base + (1 << 24), 1 << 24)
+    if depth >= 3:
+        assert g.stats['executed_steps'] < (1 << 24) // 64                   # 2^18 classes or fewer, a few updates each
+    same_as_oracle(eng, net, space, base + (1 << 25) + 999, (1 << 23) + 12345)
+    same_as_oracle(eng, net, space, 0, 1 << 23, max_t=12)
+
+
+def test_a_full_near_cycle_list_restarts_shallower(eng):
+    os.environ['BSX_CUBE_NEAR_CAP'] = '3'
+    n = 20
+    names = ['x{}'.format(i) for i in range(n)]
+    # two layers feeding eight self-loops: everything is at a fixed point after two updates, every deep class is listed
+    lines = ['nodes:'] + ['    - ' + v for v in names] + ['', 'update rules:']
+    for i in range(n):
+        if i < 8: rule = '{} or {}'.format(names[i], names[8 + i % 6])
+        elif i < 14: rule = names[14 + i % 6]
+        else: rule = '{0} and not {0}'.format(names[i])
+        lines.append('    {}: {}'.format(names[i], rule))
+    lines += ['', 'initial state:'] + ['    {}: any'.format(v) for v in names]
+    net, space = setup(eng, '\n'.join(lines) + '\n', np.inf)
+    same_as_oracle(eng, net, space, 0, 1 << n, max_t=np.inf)
+    os.environ.pop('BSX_CUBE_NEAR_CAP')
+    net, space = setup(eng, '\n'.join(lines) + '\n', np.inf)                  # (fresh engine state: no depth cap remembered)
+    same_as_oracle(eng, net, space, 0, 1 << n, max_t=np.inf)
+
+
+@pytest.mark.parametrize('seed', range(64))
+def test_deep_levels_equal_plain_enumeration_on_random_spaces(eng, seed):
+    """Differential fuzz of the level passes: sparse networks (K = 1 and 2, where influence dies out over a few
+    updates), fixed nodes, tight caps, forced depths; against the plain enumeration."""
+    import random
+    rng = random.Random(7000 + seed)
+    n = rng.choice((18, 20, 22))
+    k = rng.choice((1, 1, 2, 2))
+    fixed = {rng.randrange(n): rng.choice('01')} if rng.random() < 0.3 else None
+    initial = {i: rng.choice('01') for i in rng.sample(range(n), 2)} if rng.random() < 0.3 else None
+    max_t = rng.choice((np.inf, 4096, 4096, 9, 5, 3))
+    max_len = rng.choice((np.inf, np.inf, 1, 2))
+    text = synth.network_yaml(n, k, 9000 + seed, initial=initial, fixed=fixed)
+    net, space = setup(eng, text, max_t)
+    total = space.n_problems
+    count = rng.randrange(min(1 << 17, total // 2), total + 1)
+    first = rng.randrange(0, total - count + 1)
+    if rng.random() < 0.5:
+        first &= ~0xFFFF
+    os.environ['BSX_CUBE_DEPTH'] = str(rng.choice((2, 3, 4, 8, 8, 16)))
+    if rng.random() < 0.25:
+        os.environ['BSX_CUBE_NEAR_CAP'] = str(rng.choice((1, 7, 100)))
+    a = eng.attract(first, count, max_t, max_len)
+    os.environ['BSX_CUBES'] = '0'
+    b = eng.attract(first, count, max_t, max_len)
     assert rows(a.table) == rows(b.table), text
     assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
     assert int(a.table['count'].sum()) + a.n_no_attractor == count
