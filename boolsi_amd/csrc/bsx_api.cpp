@@ -581,6 +581,10 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     if (std::getenv("BSX_DEBUG") && run.ctr.wave_iters)
         std::fprintf(stderr, "[bsx]   diag: kept after fresh stages %llu, lanes into pool stages %llu, kept after pool stages %llu, merged away %llu\n",
                      (unsigned long long)run.ctr.diag[0], (unsigned long long)run.ctr.diag[1], (unsigned long long)run.ctr.diag[2], (unsigned long long)run.ctr.diag[3]);
+    if (std::getenv("BSX_DEBUG") && run.ctr.phase_max[0])
+        std::fprintf(stderr, "[bsx]   diag: %u workgroups; prologue / loop / epilogue, us: mean %.1f / %.1f / %.1f, slowest %.1f / %.1f / %.1f\n", L.grid.x,
+                     run.ctr.phase_sum[0] / 100.0 / L.grid.x, run.ctr.phase_sum[1] / 100.0 / L.grid.x, run.ctr.phase_sum[2] / 100.0 / L.grid.x,
+                     run.ctr.phase_max[0] / 100.0, run.ctr.phase_max[1] / 100.0, run.ctr.phase_max[2] / 100.0);
     if (!merged) return BSX_OK;                 // results discarded (discovery): a full log does not matter
     if (run.ctr.table_inserts) h->table_dirty = true;
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");

@@ -91,6 +91,8 @@ struct Counters {               // zeroed before every launch
     unsigned long long table_inserts;   // records that went to the HBM attractor table (the log was full)
     unsigned int table_overflow;        // ... and did not find a slot there
     unsigned int pad3;
+    unsigned long long phase_sum[3];    // diagnostic (BSX_DIAG builds): pool kernel, 100 MHz ticks summed over workgroups: prologue, loop, epilogue
+    unsigned long long phase_max[3];    // ... and the slowest workgroup's
     unsigned long long near_classes;    // deep cube pass: classes whose common state F^depth is a cycle state (listed, see AttractParams::near)
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic

@@ -70,6 +70,9 @@ template <int NW, int K, int LM, bool CUBE>
 __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool(const AttractParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
+#ifdef BSX_DIAG
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
@@ -190,7 +193,14 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     unsigned long long extra_ref = 0;
     cnt_t n_none = 0, n_capfail = 0;
     uint32_t nexec = 0;
-    WaveQueue q{0, 0, true};
+    // work queue: every wave's first chunk is fixed (wave w of the grid takes chunk w), only the chunks after those
+    // come from the shared cursor -- a small pass has no traffic on that one address at all
+    const uint64_t first_dyn = (uint64_t)gridDim.x * kPoolWaves * P.chunk;
+    WaveQueue q{0, 0, P.count > first_dyn};
+    {
+        const uint64_t b = ((uint64_t)blockIdx.x * kPoolWaves + wave) * P.chunk;
+        if (b < P.count) { q.next = b; q.end = (b + P.chunk < P.count) ? b + P.chunk : P.count; }
+    }
     uint32_t head = 0, count = 0;                           // pool ring (uniform)
 #ifdef BSX_DIAG
     unsigned long long dbg_iters = 0, dbg_fresh = 0, dbg_fresh_keep = 0, dbg_pool_in = 0, dbg_pool_keep = 0, dbg_merged = 0;
@@ -286,6 +296,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         }
     };
 
+#ifdef BSX_DIAG
+    const unsigned long long dbg_t1 = wall_clock64();
+#endif
     for (;;) {
         const bool input = q.more || q.next < q.end;
         if (!input && count == 0) break;
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         } else {
             // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
             if (q.next == q.end) {
-                const uint64_t b = grab_chunk(&P.ctr->cursor, P.chunk, (int)lane);
+                const uint64_t b = first_dyn + grab_chunk(&P.ctr->cursor, P.chunk, (int)lane);
                 if (b >= P.count) { q.more = false; continue; }
                 q.next = b; q.end = (b + P.chunk < P.count) ? b + P.chunk : P.count;
             }
@@ -592,15 +605,35 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 
     // ---- epilogue: workgroup accumulators -> one log record per attractor and workgroup
     __syncthreads();
-    for (uint32_t a = threadIdx.x; a < kAccs; a += blockDim.x) {
+#ifdef BSX_DIAG
+    const unsigned long long dbg_t2 = wall_clock64();
+#endif
+    // (wave 0: lane a owns accumulator a; the workgroup's records take one step of the log cursor)
+    static_assert(kAccs == 64, "one lane per accumulator");
+    if (wave == 0) {
+        const uint32_t a = lane;
         const unsigned long long cn = acc_cnt[a];
-        if (!cn) continue;
-        uint32_t k[NW];
+        const uint64_t nb = __ballot(cn != 0);
+        if (nb) {
+            unsigned long long at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&P.ctr->log_cursor, (unsigned long long)__popcll(nb));
+            const unsigned long long at = bcast64(at0, 0) + __popcll(nb & ((1ull << lane) - 1ull));
+            if (cn) {
+                const unsigned long long sl = acc_sl[a];
+                if (at < P.log_cap) {
+                    LogRec r;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) k[w] = keytab[a * NW + w];
-        const unsigned long long sl = acc_sl[a];
-        log_append<NW>(P, k, lamtab[a], cn, sl, acc_sl2[a], acc_sl2h[a]);
-        extra_ref += sl + cn * lamtab[a];                                       // + lambda each (model.py:201)
+                    for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) r.key[w] = keytab[a * NW + w];
+                    r.length = lamtab[a]; r.pad = 0; r.count = cn; r.sum_l = sl; r.sum_l2_lo = acc_sl2[a]; r.sum_l2_hi = acc_sl2h[a];
+                    P.log[at] = r;
+                } else {
+                    atomicOr(&P.ctr->log_overflow, 1u);
+                }
+                extra_ref += sl + cn * lamtab[a];                                   // + lambda each (model.py:201)
+            }
+        }
     }
 #ifdef BSX_DIAG
     if (lane == 0) {
@@ -608,10 +641,32 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         atomicAdd(&P.ctr->diag[0], dbg_fresh_keep); atomicAdd(&P.ctr->diag[1], dbg_pool_in);
         atomicAdd(&P.ctr->diag[2], dbg_pool_keep); atomicAdd(&P.ctr->diag[3], dbg_merged);
     }
+    if (threadIdx.x == 0) {
+        const unsigned long long dbg_t3 = wall_clock64();
+        atomicAdd(&P.ctr->phase_sum[0], dbg_t1 - dbg_t0); atomicMax(&P.ctr->phase_max[0], dbg_t1 - dbg_t0);
+        atomicAdd(&P.ctr->phase_sum[1], dbg_t2 - dbg_t1); atomicMax(&P.ctr->phase_max[1], dbg_t2 - dbg_t1);
+        atomicAdd(&P.ctr->phase_sum[2], dbg_t3 - dbg_t2); atomicMax(&P.ctr->phase_max[2], dbg_t3 - dbg_t2);
+    }
 #endif
-    wave_atomic_add(&P.ctr->steps_ref, extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t), (int)lane);
-    wave_atomic_add(&P.ctr->steps_exec, (unsigned long long)nexec, (int)lane);
-    wave_atomic_add(&P.ctr->n_none, (unsigned long long)n_none, (int)lane);
+    // counters: summed over the workgroup in LDS first (the accumulators are free now), one global atomic each
+    __syncthreads();
+    if (threadIdx.x < 3) acc_sl2[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const unsigned long long w_ref = wave_sum(extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t));
+        const unsigned long long w_exec = wave_sum((unsigned long long)nexec), w_none = wave_sum((unsigned long long)n_none);
+        if (lane == 0) {
+            if (w_ref) atomicAdd(&acc_sl2[0], w_ref);
+            if (w_exec) atomicAdd(&acc_sl2[1], w_exec);
+            if (w_none) atomicAdd(&acc_sl2[2], w_none);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (acc_sl2[0]) atomicAdd(&P.ctr->steps_ref, acc_sl2[0]);
+        if (acc_sl2[1]) atomicAdd(&P.ctr->steps_exec, acc_sl2[1]);
+        if (acc_sl2[2]) atomicAdd(&P.ctr->n_none, acc_sl2[2]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
