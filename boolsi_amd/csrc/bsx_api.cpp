@@ -31,6 +31,7 @@ hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t sh
 hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
 size_t pool_extra_bytes(uint32_t nw);
 hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
+hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw, uint32_t* out, hipStream_t stream);
 hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, const DevSpace& sp,
                           uint64_t n_states, uint32_t* succ, uint32_t warm_steps);
 hipError_t launch_fg_double(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t cus, hipStream_t st);
@@ -564,6 +565,17 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     // lean / pool kernels write at most one record per workgroup and cached attractor)
     P.table = (merged && !fast && h->table_slots) ? h->d_table.p : nullptr;
     P.table_mask = h->table_slots ? h->table_slots - 1 : 0;
+    const bool lists = kind == kPassPool && P.merge == 3 && P.cube_depth > 1;
+    if (lists) {
+        // classes for the level below: one segment per workgroup (P.near_cap = the caller's total, split here)
+        const uint32_t nw = h->net.nw;
+        P.near_cap = std::max<uint64_t>(1, P.near_cap / L.grid.x);
+        if (const char* e = std::getenv("BSX_CUBE_NEAR_CAP")) P.near_cap = (uint64_t)std::max(1, std::atoi(e));    // (tests: force the shallower restart)
+        HIPCHK(h, h->d_near_seg.reserve((size_t)L.grid.x * P.near_cap * nw));
+        HIPCHK(h, h->d_near_counts.reserve(L.grid.x));
+        P.near = h->d_near_seg.p;
+        P.near_counts = h->d_near_counts.p;
+    }
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (kind == kPassPool) HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
@@ -573,6 +585,10 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
+    if (lists && run.ctr.near_classes && !run.ctr.near_overflow) {
+        HIPCHK(h, h->d_near_list.reserve((size_t)run.ctr.near_classes * h->net.nw));
+        HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, L.grid.x, P.near_cap, h->net.nw, h->d_near_list.p, h->stream));
+    }
     if (std::getenv("BSX_DEBUG"))
         std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu stragglers, %.3f ms (BSX_DIAG build: %llu wave iterations, %llu service rounds)\n",
                      kind == kPassPool ? "pool" : fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
@@ -1094,8 +1110,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         const uint64_t cap_rel = max_t == BSX_T_INF ? BSX_T_INF : max_t - tp;
         const uint32_t cap_rel32 = (cap_rel == BSX_T_INF || cap_rel >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)cap_rel;
         const uint64_t list_cap = 1ull << 20;                   // unresolved classes per pass
-        uint64_t near_cap = 1ull << 22;                         // classes a deep pass may hand to the level below
-        if (const char* e = std::getenv("BSX_CUBE_NEAR_CAP")) near_cap = (uint64_t)std::max(1, std::atoi(e));     // (tests: force the shallower restart)
+        const uint64_t near_cap = 1ull << 23;                   // classes a deep pass may hand to the level below (split over its workgroups)
         if (h->d_strag.n < list_cap * rec_words) HIPCHK(h, h->d_strag.alloc(list_cap * rec_words));
         const uint32_t fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
 
@@ -1147,15 +1162,10 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 Q.cube_shift = c1.a - r_here;
                 Q.cube_depth = d;
                 Q.entry_shift = k_bits;
-                Q.entries = is_top ? nullptr : h->d_near[(d + 1) & 1].p;
-                Q.near = nullptr;
-                Q.near_cap = 0;
-                if (d > 1) {
-                    DevBuf<uint32_t>& nb = h->d_near[d & 1];
-                    if (nb.n < near_cap * nw) HIPCHK(h, nb.alloc(near_cap * nw));
-                    Q.near = nb.p;
-                    Q.near_cap = near_cap;
-                }
+                Q.entries = is_top ? nullptr : h->d_near_list.p;        // (packed by the pass above)
+                Q.near = nullptr;                                       // (segments: launch_attract_pass)
+                Q.near_counts = nullptr;
+                Q.near_cap = d > 1 ? near_cap : 0;
                 for (int w = 0; w < kMaxW32; ++w) { Q.cube_umask[w] = c1.umask[w]; Q.cube_free[w] = c1.free_mask[w]; }
                 Q.fast_steps = fast_steps;
                 Q.per_problem = nullptr;
@@ -1169,7 +1179,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                 kernel_ms += r.ms; ++launches; steps_exec += r.ctr.steps_exec;
                 if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] cube 2^%u at digit value %llu: depth %u%s, %u digits here (%u relevant), %llu classes, %llu near a cycle, %llu unresolved\n", c1.a, (unsigned long long)c1.d_lo, d, is_top ? " (top)" : "", k_bits, r_here, (unsigned long long)Q.count, (unsigned long long)r.ctr.near_classes, (unsigned long long)r.ctr.straggler_classes);
                 if (r.ctr.straggler_overflow) { give_up = true; break; }    // too many unresolved classes: not a space for cubes
-                if (r.ctr.near_classes > near_cap) { top = d - 1; h->cube_depth_cap = top; lower = true; break; }   // start over, shallower
+                if (r.ctr.near_overflow) { top = d - 1; h->cube_depth_cap = top; lower = true; break; }     // start over, shallower
                 // a level whose classes mostly sit next to a cycle only adds work: later blocks stop above it
                 if (d > 1 && 2 * r.ctr.near_classes > Q.count) h->cube_depth_cap = d - 1;
                 n_entries = r.ctr.near_classes;

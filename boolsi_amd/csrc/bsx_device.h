@@ -90,7 +90,7 @@ struct Counters {               // zeroed before every launch
     unsigned int pad;
     unsigned long long table_inserts;   // records that went to the HBM attractor table (the log was full)
     unsigned int table_overflow;        // ... and did not find a slot there
-    unsigned int pad3;
+    unsigned int near_overflow;         // deep cube pass: some workgroup listed more classes than its segment holds
     unsigned long long phase_sum[3];    // diagnostic (BSX_DIAG builds): pool kernel, 100 MHz ticks summed over workgroups: prologue, loop, epilogue
     unsigned long long phase_max[3];    // ... and the slowest workgroup's
     unsigned long long near_classes;    // deep cube pass: classes whose common state F^depth is a cycle state (listed, see AttractParams::near)
@@ -174,14 +174,17 @@ struct AttractParams {
     // Deep cube pass (DESIGN.md "deeper collapse"): the class digits are those F^depth still depends on, the
     // fresh stage makes `cube_depth` updates before the first lookup, and a class whose common state F^depth(x)
     // is a cached cycle state -- its members enter the cycle at different times <= depth -- is not accounted but
-    // listed by its representative's initial state in `near` (near_cap states of nw words; Counters::near_classes
-    // counts them, also past the capacity).  The host runs the listed classes again one level down:
+    // listed by its representative's initial state: workgroup g appends to its own segment near[g * near_cap ..]
+    // (near_cap states of nw words, no global atomics) and leaves its count in near_counts[g]; k_compact_near
+    // then packs the segments into one list.  Counters::near_classes = the total, near_overflow = a segment was
+    // too small.  The host runs the listed classes again one level down:
     // entries != null: work item i is sub-assignment i & (2^entry_shift - 1) of the digits this level adds,
     // on top of the state entries[(i >> entry_shift) * nw ..].
     uint32_t cube_depth;        // >= 1 (1 = one update, then lookups: the plain cube pass)
     uint32_t entry_shift;
     const uint32_t* entries;
     uint32_t* near;
+    uint32_t* near_counts;
     uint64_t near_cap;
     // general kernel, discovery from explicit states: work item i starts at states[i * nw ..] (no enumeration)
     const uint32_t* states;

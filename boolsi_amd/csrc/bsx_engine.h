@@ -76,7 +76,9 @@ struct bsx_engine {
     uint64_t table_slots = 0;
     bool table_dirty = false;
     bsx::DevBuf<uint32_t> d_strag;
-    bsx::DevBuf<uint32_t> d_near[2];    // deep cube passes: listed classes of one level / the level below (ping-pong)
+    bsx::DevBuf<uint32_t> d_near_seg;   // deep cube passes: classes listed for the level below, one segment per workgroup,
+    bsx::DevBuf<uint32_t> d_near_counts;    // the segments' fill counts,
+    bsx::DevBuf<uint32_t> d_near_list;  // and the packed list the next level reads
     uint32_t cube_depth_cap = 0;        // 0 = no experience yet; else the deepest level that paid off on this problem
     bsx::DevBuf<uint32_t> d_life;       // cube collapse: per-digit influence lifetimes (ordering heuristic)
     bsx::DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             if (differs) cache_insert_lds<NW>(lc, cmask, rep, e[NW + 1], key, (tw & kTagMask) | kTagRep);
         }
         lc[1] = n_in;
+        lc[2] = 0;                          // classes this workgroup lists for the level below
     }
     __syncthreads();
     // uniform: some member may have mu = 0 (with a warm-up the search starts at s(T_p), which all members share)
@@ -441,13 +442,13 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 if (nb) {
                     uint32_t S0[NW];
                     fresh_state(fresh_pos, near, S0);
-                    unsigned long long at0 = 0;
-                    if (lane == 0) at0 = atomicAdd(&P.ctr->near_classes, (unsigned long long)__popcll(nb));
-                    const uint32_t at_lo = __builtin_amdgcn_readfirstlane((uint32_t)at0), at_hi = __builtin_amdgcn_readfirstlane((uint32_t)(at0 >> 32));
-                    const unsigned long long at = (((unsigned long long)at_hi << 32) | at_lo) + __popcll(nb & ((1ull << lane) - 1ull));
+                    uint32_t at0 = 0;
+                    if (lane == 0) at0 = atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&lc[2], (uint32_t)__popcll(nb));    // the workgroup's own segment
+                    const uint32_t at = __builtin_amdgcn_readfirstlane(at0) + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
                     if (near && at < P.near_cap) {
+                        uint32_t* seg = P.near + ((uint64_t)blockIdx.x * P.near_cap + at) * NW;
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) P.near[at * NW + w] = S0[w];
+                        for (int w = 0; w < NW; ++w) seg[w] = S0[w];
                     }
                 }
                 if (near) { live = false; res = 0; }
@@ -663,10 +664,44 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if constexpr (cube) {
+            if (P.near_counts) {
+                const uint32_t listed = lc[2];
+                P.near_counts[blockIdx.x] = listed;
+                if (listed) atomicAdd(&P.ctr->near_classes, (unsigned long long)listed);
+                if (listed > P.near_cap) atomicOr(&P.ctr->near_overflow, 1u);
+            }
+        }
         if (acc_sl2[0]) atomicAdd(&P.ctr->steps_ref, acc_sl2[0]);
         if (acc_sl2[1]) atomicAdd(&P.ctr->steps_exec, acc_sl2[1]);
         if (acc_sl2[2]) atomicAdd(&P.ctr->n_none, acc_sl2[2]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deep cube passes: the workgroups' segments of listed classes -> one contiguous list (block g copies segment g
+// to where the segments before it end).
+__global__ __launch_bounds__(256) void k_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg,
+                                                      uint64_t cap, uint32_t nw, uint32_t* out) {
+    __shared__ unsigned long long before;
+    if (threadIdx.x == 0) before = 0;
+    __syncthreads();
+    unsigned long long part = 0;
+    for (uint32_t g = threadIdx.x; g < blockIdx.x; g += blockDim.x) part += counts[g] < cap ? counts[g] : cap;
+    if (part) atomicAdd(&before, part);
+    __syncthreads();
+    const uint64_t mine = counts[blockIdx.x] < cap ? counts[blockIdx.x] : cap;
+    const uint32_t* src = seg + (uint64_t)blockIdx.x * cap * nw;
+    uint32_t* dst = out + before * nw;
+    for (uint64_t i = threadIdx.x; i < mine * nw; i += blockDim.x) dst[i] = src[i];
+    (void)n_seg;
+}
+
+hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw,
+                               uint32_t* out, hipStream_t stream) {
+    if (!n_seg) return hipSuccess;
+    hipLaunchKernelGGL(k_compact_near, dim3(n_seg), dim3(256), 0, stream, seg, counts, n_seg, cap, nw, out);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
