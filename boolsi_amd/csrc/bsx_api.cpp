@@ -555,7 +555,18 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     }
     const Launch L = plan_persistent(h, P.count, shmem);
     P.chunk = L.chunk;
-    if (const char* c = std::getenv("BSX_CHUNK")) P.chunk = (uint32_t)std::max(64, std::atoi(c));     // tuning knob
+    if (kind == kPassPool) {
+        // fixed first share per wave; only large passes leave a quarter to the shared cursor, in 4096-class pieces
+        const uint64_t n_waves = (uint64_t)L.grid.x * (kPoolBlockThreads / 64);
+        if (P.count < (1ull << 25)) {
+            P.chunk_first = ((P.count + n_waves - 1) / n_waves + 63) / 64 * 64;
+            P.chunk = 0;
+        } else {
+            P.chunk_first = (P.count - P.count / 4) / n_waves / 64 * 64;
+            P.chunk = 4096;
+        }
+    }
+    if (const char* c = std::getenv("BSX_CHUNK")) { P.chunk = (uint32_t)std::max(64, std::atoi(c)); P.chunk_first = P.chunk; }     // tuning knob
     const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
     const uint64_t log_cap = waves * kTableSlots + (1u << 16);
     if (d_log.n < log_cap) HIPCHK(h, d_log.alloc(log_cap));

@@ -7,6 +7,7 @@ namespace bsx {
 constexpr int kWave = 64;
 constexpr int kBlock = 512;                 // 8 waves per workgroup share one LUT + cache mirror in LDS
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kPoolBlockThreads = 768;      // the pool kernel's workgroup (bsx_pool.hip)
 constexpr int kMaxW32 = 8;                  // 32-bit words per state (n <= 256)
 constexpr int kMaxMuxK = 6;                 // nodes with more predecessors take the "wide" path
 constexpr int kTableSlots = 64;             // per-wave attractor table: one slot per lane (registers)
@@ -142,6 +143,7 @@ struct AttractParams {
     DevSpace sp;
     uint64_t count;
     uint32_t chunk;             // problems per dequeue
+                                // (pool kernel: per dequeue AFTER the wave's fixed first share, 0 = there is nothing after it)
     uint32_t cap_rel_inf;       // 1: max_t is infinite
     uint64_t max_t;             // absolute cap (valid when !cap_rel_inf)
     uint64_t max_len;           // attractor length cap (UINT64_MAX = none)
@@ -180,6 +182,10 @@ struct AttractParams {
     // too small.  The host runs the listed classes again one level down:
     // entries != null: work item i is sub-assignment i & (2^entry_shift - 1) of the digits this level adds,
     // on top of the state entries[(i >> entry_shift) * nw ..].
+    uint64_t chunk_first;       // pool kernel: wave w of the grid starts with [w * chunk_first, (w + 1) * chunk_first); the
+                                // shared cursor hands out what lies beyond n_waves * chunk_first.  Same-address atomics
+                                // complete at some 15 ns apiece however many waves wait, so a pass must not take
+                                // more than a few hundred of them per 100 us: small passes are split evenly up front.
     uint32_t cube_depth;        // >= 1 (1 = one update, then lookups: the plain cube pass)
     uint32_t entry_shift;
     const uint32_t* entries;

@@ -40,7 +40,7 @@ namespace bsx {
 // Workgroup = 12 waves sharing one LUT and cache mirror: with n = 64 that is 39 KiB + 12 x 3.3 KiB of LDS,
 // so two workgroups fit a CU = 6 waves per SIMD, 3 from each (with 8-wave workgroups and 128-class rings
 // it was 4).  The kernel is bound by the latency of its dependent LDS round trips, so waves matter.
-constexpr int kPoolBlock = 768;
+constexpr int kPoolBlock = kPoolBlockThreads;
 constexpr int kPoolWaves = kPoolBlock / 64;
 constexpr uint32_t kPoolCap = 112;              // classes per wave (ring buffer; > 64 + what a fresh stage leaves)
 constexpr uint32_t kPoolGroup = 64;             // problems loaded together = lanes
@@ -196,11 +196,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     uint32_t nexec = 0;
     // work queue: every wave's first chunk is fixed (wave w of the grid takes chunk w), only the chunks after those
     // come from the shared cursor -- a small pass has no traffic on that one address at all
-    const uint64_t first_dyn = (uint64_t)gridDim.x * kPoolWaves * P.chunk;
-    WaveQueue q{0, 0, P.count > first_dyn};
+    const uint64_t first_dyn = (uint64_t)gridDim.x * kPoolWaves * P.chunk_first;
+    WaveQueue q{0, 0, P.chunk != 0 && P.count > first_dyn};
     {
-        const uint64_t b = ((uint64_t)blockIdx.x * kPoolWaves + wave) * P.chunk;
-        if (b < P.count) { q.next = b; q.end = (b + P.chunk < P.count) ? b + P.chunk : P.count; }
+        const uint64_t b = ((uint64_t)blockIdx.x * kPoolWaves + wave) * P.chunk_first;
+        if (b < P.count) { q.next = b; q.end = (b + P.chunk_first < P.count) ? b + P.chunk_first : P.count; }
     }
     uint32_t head = 0, count = 0;                           // pool ring (uniform)
 #ifdef BSX_DIAG
@@ -352,6 +352,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         } else {
             // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
             if (q.next == q.end) {
+                // (a look before the atomic: reads of the cursor do not queue up the way its atomics do)
+                if (first_dyn + *(volatile unsigned long long*)&P.ctr->cursor >= P.count) { q.more = false; continue; }
                 const uint64_t b = first_dyn + grab_chunk(&P.ctr->cursor, P.chunk, (int)lane);
                 if (b >= P.count) { q.more = false; continue; }
                 q.next = b; q.end = (b + P.chunk < P.count) ? b + P.chunk : P.count;
