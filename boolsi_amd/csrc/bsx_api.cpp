@@ -352,6 +352,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     h->fast_ok = true;
     h->cube_depth_cap = 0;
+    h->life_valid = 0;
     h->h_journal.clear();
     h->journal_stale = true;
     h->fast_steps = 0;
@@ -616,6 +617,19 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     if (run.ctr.table_inserts) h->table_dirty = true;
     if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
     if (run.ctr.table_overflow) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity (device table full)");
+    if (kind == kPassPool && P.merge == 3) {    // cube pass: the sums came back with the counters
+        LogRec recs[64];
+        size_t n_recs = 0;
+        for (uint32_t a = 0; a < 64; ++a) {
+            if (!run.ctr.acc_cnt[a]) continue;
+            LogRec& r = recs[n_recs++];
+            for (int w = 0; w < kMaxW32; ++w) r.key[w] = run.ctr.acc_key[a][w];
+            r.length = run.ctr.acc_len[a]; r.pad = 0; r.count = run.ctr.acc_cnt[a]; r.sum_l = run.ctr.acc_sl[a];
+            r.sum_l2_lo = run.ctr.acc_sl2_lo[a]; r.sum_l2_hi = run.ctr.acc_sl2_hi[a];
+        }
+        merge_records(*merged, recs, n_recs, h->net.nw);
+        return BSX_OK;
+    }
     const uint64_t n_log = std::min<uint64_t>(run.ctr.log_cursor, log_cap);
     std::vector<LogRec> log(n_log);
     if (n_log) HIPCHK(h, hipMemcpy(log.data(), d_log.p, n_log * sizeof(LogRec), hipMemcpyDeviceToHost));
@@ -795,18 +809,26 @@ void cube_levels(const bsx_engine* h, const Cube& c, uint32_t max_depth, std::ve
 int order_cube_digits(bsx_handle h, Cube& c) {
     const uint32_t r = (uint32_t)c.rel.size();
     if (r < 2 || r > 64 || (std::getenv("BSX_CUBE_ORDER") && std::getenv("BSX_CUBE_ORDER")[0] == '0')) return BSX_OK;
-    LifetimeParams L{};
-    L.net = h->net;
-    for (int w = 0; w < kMaxW32; ++w) { L.fixmask[w] = h->sp.fixmask[w]; L.fixval[w] = h->sp.fixval[w]; L.base[w] = c.base[w]; L.free_mask[w] = c.free_mask[w]; }
-    L.n_digits = r;
-    for (uint32_t q = 0; q < r; ++q) L.node[q] = h->h_any[c.rel[q]];
-    HIPCHK(h, h->d_life.reserve(64));
-    HIPCHK(h, hipMemsetAsync(h->d_life.p, 0, 64 * sizeof(uint32_t), h->stream));
-    L.out = h->d_life.p;
-    HIPCHK(h, launch_digit_lifetimes((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, h->shmem, h->stream, L));
+    uint64_t need = 0;
+    for (uint32_t q = 0; q < r; ++q) need |= 1ull << c.rel[q];
+    if (need & ~h->life_valid) {
+        LifetimeParams L{};
+        L.net = h->net;
+        for (int w = 0; w < kMaxW32; ++w) { L.fixmask[w] = h->sp.fixmask[w]; L.fixval[w] = h->sp.fixval[w]; L.base[w] = c.base[w]; L.free_mask[w] = c.free_mask[w]; }
+        L.n_digits = r;
+        for (uint32_t q = 0; q < r; ++q) L.node[q] = h->h_any[c.rel[q]];
+        HIPCHK(h, h->d_life.reserve(64));
+        HIPCHK(h, hipMemsetAsync(h->d_life.p, 0, 64 * sizeof(uint32_t), h->stream));
+        L.out = h->d_life.p;
+        HIPCHK(h, launch_digit_lifetimes((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, h->shmem, h->stream, L));
+        uint32_t measured[64];
+        HIPCHK(h, hipMemcpyAsync(measured, h->d_life.p, sizeof(measured), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (uint32_t q = 0; q < r; ++q) h->life_cache[c.rel[q]] = measured[q];
+        h->life_valid |= need;
+    }
     uint32_t life[64];
-    HIPCHK(h, hipMemcpyAsync(life, h->d_life.p, sizeof(life), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (uint32_t q = 0; q < r; ++q) life[q] = h->life_cache[c.rel[q]];
     std::vector<uint32_t> idx(r);
     for (uint32_t q = 0; q < r; ++q) idx[q] = q;
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return life[x] < life[y]; });

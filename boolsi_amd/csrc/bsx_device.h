@@ -94,6 +94,12 @@ struct Counters {               // zeroed before every launch
     unsigned int near_overflow;         // deep cube pass: some workgroup listed more classes than its segment holds
     unsigned long long phase_sum[3];    // diagnostic (BSX_DIAG builds): pool kernel, 100 MHz ticks summed over workgroups: prologue, loop, epilogue
     unsigned long long phase_max[3];    // ... and the slowest workgroup's
+    // cube passes of the pool kernel: the workgroups add their LDS accumulators up here (slot = the attractor's
+    // position in the cache mirror, the same in every workgroup of a launch) instead of writing log records:
+    // the results come back with this struct
+    unsigned long long acc_cnt[64], acc_sl[64], acc_sl2_lo[64], acc_sl2_hi[64];
+    unsigned int acc_len[64];
+    unsigned int acc_key[64][kMaxW32];
     unsigned long long near_classes;    // deep cube pass: classes whose common state F^depth is a cycle state (listed, see AttractParams::near)
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic

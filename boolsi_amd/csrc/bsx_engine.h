@@ -79,6 +79,8 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_near_seg;   // deep cube passes: classes listed for the level below, one segment per workgroup,
     bsx::DevBuf<uint32_t> d_near_counts;    // the segments' fill counts,
     bsx::DevBuf<uint32_t> d_near_list;  // and the packed list the next level reads
+    uint32_t life_cache[64] = {};       // cube passes: k_digit_lifetimes per digit, measured on the first block that needed it
+    uint64_t life_valid = 0;            // (an ordering heuristic: later blocks of the problem reuse it)
     uint32_t cube_depth_cap = 0;        // 0 = no experience yet; else the deepest level that paid off on this problem
     bsx::DevBuf<uint32_t> d_life;       // cube collapse: per-digit influence lifetimes (ordering heuristic)
     bsx::DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;

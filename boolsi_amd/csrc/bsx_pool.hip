@@ -619,11 +619,23 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         const uint64_t nb = __ballot(cn != 0);
         if (nb) {
             unsigned long long at0 = 0;
-            if (lane == 0) at0 = atomicAdd(&P.ctr->log_cursor, (unsigned long long)__popcll(nb));
+            if (!cube && lane == 0) at0 = atomicAdd(&P.ctr->log_cursor, (unsigned long long)__popcll(nb));
             const unsigned long long at = bcast64(at0, 0) + __popcll(nb & ((1ull << lane) - 1ull));
             if (cn) {
                 const unsigned long long sl = acc_sl[a];
-                if (at < P.log_cap) {
+                if constexpr (cube) {
+                    // (one global atomic per sum: 64 addresses, a few hundred adds each per launch)
+                    Counters* c = P.ctr;
+                    atomicAdd(&c->acc_cnt[a], cn);
+                    atomicAdd(&c->acc_sl[a], sl);
+                    const unsigned long long lo = acc_sl2[a];
+                    const unsigned long long old = atomicAdd(&c->acc_sl2_lo[a], lo);
+                    const unsigned long long up = acc_sl2h[a] + ((old + lo < old) ? 1ull : 0ull);
+                    if (up) atomicAdd(&c->acc_sl2_hi[a], up);
+                    c->acc_len[a] = lamtab[a];                      // (every workgroup stores the same values)
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) c->acc_key[a][w] = keytab[a * NW + w];
+                } else if (at < P.log_cap) {
                     LogRec r;
 #pragma unroll
                     for (int w = 0; w < kMaxW32; ++w) r.key[w] = 0;
