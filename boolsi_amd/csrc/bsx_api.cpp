@@ -102,8 +102,9 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
     }
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
-        (e = h->d_ctr.alloc(1)) != hipSuccess) {
+        (e = h->d_ctr.alloc(1)) != hipSuccess || (e = hipHostMalloc((void**)&h->h_ctr, sizeof(Counters), hipHostMallocDefault)) != hipSuccess) {
         g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
+        if (h->h_ctr) (void)hipHostFree(h->h_ctr);
         delete h;
         return BSX_ERR_HIP;
     }
@@ -112,6 +113,7 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
     if ((e = h->d_cc_journal.alloc(kCycleJournalCap)) != hipSuccess ||
         (e = h->d_cc_claims.alloc(kCycleClaimSlots)) != hipSuccess || (e = h->d_cc_count.alloc(1)) != hipSuccess) {
         g_create_error = std::string("cycle cache allocation: ") + hipGetErrorString(e);
+        if (h->h_ctr) (void)hipHostFree(h->h_ctr);
         delete h;
         return BSX_ERR_HIP;
     }
@@ -127,6 +129,7 @@ extern "C" int bsx_destroy(bsx_handle h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     delete h;
     return BSX_OK;
 }
@@ -543,8 +546,10 @@ int lean_mirror_slots(bsx_handle h, uint32_t* slots_out) {
 
 void merge_records(MergedTable& merged, const LogRec* recs, size_t n, uint32_t nw);
 
+static double g_prof[6];      // BSX_PROFILE: host time per section of a pass, ms
 int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>& d_log, MergedTable* merged,
                         AttractRun& run) {
+    const double pt0 = now_ms();
     const bool fast = kind != kPassGeneral;
     if (!fast) h->journal_stale = true;         // the detector may publish attractors
     size_t shmem = h->shmem_attract;
@@ -588,15 +593,20 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
         P.near = h->d_near_seg.p;
         P.near_counts = h->d_near_counts.p;
     }
+    const double pt1 = now_ms();
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (kind == kPassPool) HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
     else if (kind == kPassLean) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
     else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipMemcpyAsync(&run.ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    const double pt2 = now_ms();
+    HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    run.ctr = *h->h_ctr;
+    const double pt3 = now_ms();
     HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
+    g_prof[0] += pt1 - pt0; g_prof[1] += pt2 - pt1; g_prof[2] += pt3 - pt2; g_prof[3] += run.ms;
     if (lists && run.ctr.near_classes && !run.ctr.near_overflow) {
         HIPCHK(h, h->d_near_list.reserve((size_t)run.ctr.near_classes * h->net.nw));
         HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, L.grid.x, P.near_cap, h->net.nw, h->d_near_list.p, h->stream));
@@ -1340,6 +1350,11 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         stats->kernel_ms = kernel_ms;
         stats->kernel_launches = launches;
         stats->total_ms = now_ms() - t_begin;
+    }
+    if (std::getenv("BSX_PROFILE")) {
+        std::fprintf(stderr, "[bsx] profile: call %.3f ms; passes: setup %.3f, enqueue %.3f, wait %.3f (kernels %.3f)\n",
+                     now_ms() - t_begin, g_prof[0], g_prof[1], g_prof[2], g_prof[3]);
+        for (double& v : g_prof) v = 0;
     }
     if (limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit without closing its cycle");
     return BSX_OK;

@@ -102,6 +102,7 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
 
     bsx::DevBuf<bsx::Counters> d_ctr;
+    bsx::Counters* h_ctr = nullptr;     // pinned landing buffer for the counters of a pass
 
     // functional-graph mode (bsx_fgraph.hip): N-sized arrays, kept between calls (grow-only)
     bsx::DevBuf<uint32_t> d_fg_a, d_fg_b, d_fg_c, d_fg_warm;

@@ -146,33 +146,54 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             for (int w = 0; w < NW; ++w) midtab[i * NW + w] = m[w];
         }
     }
-    // cube pass: cached cycle states inside the block get a second mirror entry, their class representative
-    if (cube && threadIdx.x == 0) {
-        uint32_t n_in = 0;
-        for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {
-            const uint32_t* e = cbase + sl * S;
-            const uint32_t tw = e[NW];
-            if ((tw & kTagMask) == 0 || (tw & kTagRep)) continue;
-            uint32_t rep[NW], key[NW], outside = 0, differs = 0;
+    // (a deep pass hands every class with members that close to a cycle to the level below instead)
+    const uint32_t depth = (cube && P.cube_depth > 1u) ? P.cube_depth : 1u;   // uniform: updates of a fresh class before its first lookup
+    // cube pass: cached cycle states inside the block get a second mirror entry, their class representative.
+    // All threads look through the mirror; the few states found are inserted by thread 0.
+    if constexpr (cube) {
+        if (threadIdx.x == 0) { lc[1] = 0; lc[2] = 0; }     // lc[1]: cycle states inside the block, lc[2]: classes listed for the level below
+        __syncthreads();
+        if (depth == 1u && !has_warmup) {
+            constexpr uint32_t kFoundCap = kCap * R;          // slots of the states found go to wave 0's ring (not in use yet)
+            auto inside = [&](uint32_t sl) -> bool {
+                const uint32_t* e = cbase + sl * S;
+                const uint32_t tw = e[NW];
+                if ((tw & kTagMask) == 0 || (tw & kTagRep)) return false;
+                uint32_t outside = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const uint32_t st = e[w];
-                outside |= (st ^ P.sp.origin[w]) & ~P.cube_free[w];
-                rep[w] = st & ~P.cube_umask[w];
-                differs |= rep[w] ^ st;
-                key[w] = e[NW + 2 + w];
+                for (int w = 0; w < NW; ++w) outside |= (e[w] ^ P.sp.origin[w]) & ~P.cube_free[w];
+                return outside == 0;
+            };
+            lds_vu32* const found0 = (lds_vu32*)(__attribute__((address_space(3))) uint32_t*)(midtab + 64 * NW);
+            for (uint32_t sl = threadIdx.x; sl < P.cc.lds_slots; sl += blockDim.x) {
+                if (!inside(sl)) continue;
+                const uint32_t at = atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&lc[1], 1u);
+                if (at < kFoundCap) found0[at] = sl;
             }
-            if (outside) continue;
-            ++n_in;
-            if (differs) cache_insert_lds<NW>(lc, cmask, rep, e[NW + 1], key, (tw & kTagMask) | kTagRep);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t n_in = lc[1];
+                auto add_rep = [&](uint32_t sl) {
+                    const uint32_t* e = cbase + sl * S;
+                    uint32_t rep[NW], key[NW], differs = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        rep[w] = e[w] & ~P.cube_umask[w];
+                        differs |= rep[w] ^ e[w];
+                        key[w] = e[NW + 2 + w];
+                    }
+                    if (differs) cache_insert_lds<NW>(lc, cmask, rep, e[NW + 1], key, (e[NW] & kTagMask) | kTagRep);
+                };
+                if (n_in <= kFoundCap) {
+                    for (uint32_t i = 0; i < n_in; ++i) add_rep(found0[i]);
+                } else {                                    // (more than the list holds: one thread walks the mirror)
+                    for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) if (inside(sl)) add_rep(sl);
+                }
+            }
         }
-        lc[1] = n_in;
-        lc[2] = 0;                          // classes this workgroup lists for the level below
     }
     __syncthreads();
     // uniform: some member may have mu = 0 (with a warm-up the search starts at s(T_p), which all members share)
-    // (a deep pass hands every class with members that close to a cycle to the level below instead)
-    const uint32_t depth = (cube && P.cube_depth > 1u) ? P.cube_depth : 1u;   // uniform: updates of a fresh class before its first lookup
     const bool t0_lookup = cube && !has_warmup && depth == 1u && __builtin_amdgcn_readfirstlane(lc[1]) != 0;
     // cube pass: a wave's 64 classes differ in the six lowest relevant digits only; where those land in the
     // state is the same in every iteration, the rest of the class index is wave-uniform (scalar deposit)
