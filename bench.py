@@ -50,7 +50,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--log2-batch', type=int, default=40, help='log2 of problems per GPU per step')
+    ap.add_argument('--log2-batch', type=int, default=48, help='log2 of problems per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-log2-sample', type=int, default=25, help='log2 of the problems the CPU baseline runs (2^25: ~12 s on the box)')
     args = ap.parse_args()

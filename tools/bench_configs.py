@@ -62,6 +62,8 @@ def main():
         net, space = compile_problem(cfg)
         eng.set_problem(net, space)
         cpu = cpu_attract(net, space, first, min(cpu_sample, count), None if max_t == float('inf') else max_t)
+        if cpu:
+            time.sleep(0.5)         # the oracle's OpenMP threads spin for a while after their last loop: not under the GPU timings
         for path in paths:
             os.environ.pop('BSX_CUBES', None)
             if path == 'plain enumeration (BSX_CUBES=0)':

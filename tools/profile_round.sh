@@ -25,7 +25,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   tag=$(echo $grp | tr ' ' '+')
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$tag" -o run -- $PMC_CMD > "$OUT/pmc_$tag.log" 2>&1 || echo "pmc pass $tag failed"
 done
-python3 tools/pmc_read.py $OUT k_attract_pool 40 > $OUT/pmc.json
+python3 tools/pmc_read.py $OUT k_attract_pool 48 > $OUT/pmc.json
 cat $OUT/pmc.json
 if [ "$2" != "--bench-only" ]; then
   python3 tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
