@@ -786,7 +786,6 @@ void cube_levels(const bsx_engine* h, const Cube& c, uint32_t max_depth, std::ve
             if (k > (uint32_t)kMaxMuxK) {                // wide rule: varies with whatever its inputs vary with (conservative)
                 nval[i] = 2;
                 for (uint32_t j = 0; j < k; ++j) ndep[i] |= dep[preds[j]];
-                all |= ndep[i];
                 continue;
             }
             const uint64_t tt = h->h_tt0[i];
@@ -806,8 +805,12 @@ void cube_levels(const bsx_engine* h, const Cube& c, uint32_t max_depth, std::ve
             if (seen != 3u) { nval[i] = seen >> 1; continue; }
             nval[i] = 2;
             for (uint32_t j = 0; j < k; ++j) if ((sens >> j) & 1u) ndep[i] |= dep[preds[j]];
-            all |= ndep[i];
         }
+        // the origin's perturbation schedule overrides the rules at time d (model.py:68-71): constants for every member
+        for (size_t e = 0; e + 2 < h->h_sched.size(); e += 3)
+            if (h->h_sched[e] == d) { nval[h->h_sched[e + 1]] = (uint8_t)h->h_sched[e + 2]; ndep[h->h_sched[e + 1]] = 0; }
+        all = 0;
+        for (uint32_t i = 0; i < n; ++i) all |= ndep[i];
         out.push_back(all);
         val.swap(nval);
         dep.swap(ndep);
@@ -1162,7 +1165,9 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         uint32_t max_depth = 8;
         if (const char* e = std::getenv("BSX_CUBE_DEPTH")) max_depth = (uint32_t)std::max(1, std::min(16, std::atoi(e)));
         if (h->cube_depth_cap) max_depth = std::min(max_depth, h->cube_depth_cap);
-        if (tp) max_depth = 1;                                  // (with a warm-up the members part ways after s(T_p) only: one level)
+        // with a warm-up the search starts at s(T_p): classes that share F^d, d <= T_p, share every state that counts,
+        // so no class has to be handed down -- one pass at the best such depth
+        if (tp) max_depth = (uint32_t)std::min<uint64_t>(max_depth, tp);
         max_depth = std::max(1u, std::min(max_depth, fast_steps > 1 ? fast_steps - 1 : 1u));
         std::vector<uint64_t> rel_mask;
         cube_levels(h, c1, max_depth, rel_mask);

@@ -412,18 +412,20 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             }
             if constexpr (cube) {
                 if (depth > 1u) {
-                    // deep pass: the members of a class share F^depth(x), not the states before it
-                    deep_fresh = true;
-                    if (live) {
-                        for (uint32_t i = 1; i < depth; ++i) {
+                    // deep pass: the members of a class share F^depth(x), not the states before it.  With a warm-up
+                    // (depth <= T_p, the host sees to that) they share s(T_p) and so all that counts: nothing to list.
+                    deep_fresh = !has_warmup;
+                    for (uint32_t i = 1; i < depth; ++i) {
+                        ++t;
+                        if (live) {
                             uint32_t nx[NW];
                             net_step<NW, K>(nv, A, fm0, fv0, nx, has_fixed);
+                            if (has_warmup) apply_perturbations<NW>(P.sp, (uint32_t)((int32_t)tp + t), 0ull, nx);      // (t <= 0 here)
 #pragma unroll
                             for (int w = 0; w < NW; ++w) A[w] = nx[w];
                         }
-                        nexec += depth - 1u;
                     }
-                    t += (int32_t)(depth - 1u);
+                    if (live) nexec += depth - 1u;
                 }
             }
 #ifdef BSX_DIAG
