@@ -5,8 +5,9 @@ a synthetic 64-node network (K = 2, seed 64, every node 'any'; the 2^64 space is
 index range), at 1/2/4/8 GPUs.
 
 One "step" = one pass of the hot path (bsx_run_attract: enumerate -> step -> detect -> aggregate)
-over one batch of 2^LOG2_BATCH consecutive problem indices per GPU, folded into the rank's running
-attractor table.  Weak scaling: every rank gets its own batch each step.  After the LAST step the
+over one batch of 2^LOG2_BATCH consecutive problem indices per GPU (default 2^48, the most one call takes),
+folded into the rank's running attractor table.  The engine runs such a batch as a cascade of cube passes
+(DESIGN.md "Deeper collapse"): a few launches of k_attract_pool per step, the first one dominant.  Weak scaling: every rank gets its own batch each step.  After the LAST step the
 per-rank tables are merged with one RCCL all-gather (inside the timed region; N > 1 only).  Network
 tables live in HBM before the timed region; initial states are generated on the device from the
 index, so nothing crosses PCIe inside a step except the (< 1 MB) attractor log.
@@ -20,7 +21,8 @@ Accounting (what each number counts):
                                         what a stepping implementation would have had to do.
   attractors_per_s                      problems resolved per second (BASELINE.json's second metric).
   roofline                              SURVEY 8(d) basis: 0.25 B per EXECUTED node update, per launch of the
-                                        dominant kernel / its HIP-event duration, vs 8 TB/s.  <= 1 by
+                                        dominant kernel (averaged over its launches, all levels of the cascade)
+                                        / its HIP-event duration, vs 8 TB/s.  <= 1 by
                                         construction.  The kernel keeps states in registers/LDS, so its real
                                         HBM traffic (`traffic`, from a separate PMC pass) is ~1e-4 of that and
                                         HBM is not what limits it: `issue_bound` gives what the PMC counters show
