@@ -562,14 +562,16 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     const Launch L = plan_persistent(h, P.count, shmem);
     P.chunk = L.chunk;
     if (kind == kPassPool) {
-        // fixed first share per wave; only large passes leave a quarter to the shared cursor, in 4096-class pieces
+        // Cube passes under 2^28 classes: even fixed shares, no cursor traffic (their classes cost about the same
+        // everywhere).  Larger ones and plain tiles, whose cost per problem varies by region: every wave starts
+        // with one piece and takes the rest from the cursor, 4096 at a time (measured on config 3's plain tiles:
+        // fixed three-quarter shares 2.5 ms against 1.9 ms; a read of the cursor before each atomic cost 0.5 ms more).
         const uint64_t n_waves = (uint64_t)L.grid.x * (kPoolBlockThreads / 64);
-        if (P.count < (1ull << 25)) {
+        if (P.merge == 3 && P.count < (1ull << 28)) {
             P.chunk_first = ((P.count + n_waves - 1) / n_waves + 63) / 64 * 64;
             P.chunk = 0;
         } else {
-            P.chunk_first = (P.count - P.count / 4) / n_waves / 64 * 64;
-            P.chunk = 4096;
+            P.chunk_first = P.chunk;
         }
     }
     if (const char* c = std::getenv("BSX_CHUNK")) { P.chunk = (uint32_t)std::max(64, std::atoi(c)); P.chunk_first = P.chunk; }     // tuning knob
@@ -824,7 +826,8 @@ int order_cube_digits(bsx_handle h, Cube& c) {
     if (r < 2 || r > 64 || (std::getenv("BSX_CUBE_ORDER") && std::getenv("BSX_CUBE_ORDER")[0] == '0')) return BSX_OK;
     uint64_t need = 0;
     for (uint32_t q = 0; q < r; ++q) need |= 1ull << c.rel[q];
-    if (need & ~h->life_valid) {
+    // (a pass of 2^26 classes or more takes milliseconds: worth the 30 us of measuring on this very block)
+    if ((need & ~h->life_valid) || r >= 26) {
         LifetimeParams L{};
         L.net = h->net;
         for (int w = 0; w < kMaxW32; ++w) { L.fixmask[w] = h->sp.fixmask[w]; L.fixval[w] = h->sp.fixval[w]; L.base[w] = c.base[w]; L.free_mask[w] = c.free_mask[w]; }

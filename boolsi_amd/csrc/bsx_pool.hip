@@ -373,8 +373,6 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         } else {
             // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
             if (q.next == q.end) {
-                // (a look before the atomic: reads of the cursor do not queue up the way its atomics do)
-                if (first_dyn + *(volatile unsigned long long*)&P.ctr->cursor >= P.count) { q.more = false; continue; }
                 const uint64_t b = first_dyn + grab_chunk(&P.ctr->cursor, P.chunk, (int)lane);
                 if (b >= P.count) { q.more = false; continue; }
                 q.next = b; q.end = (b + P.chunk < P.count) ? b + P.chunk : P.count;
