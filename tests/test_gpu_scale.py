@@ -114,3 +114,39 @@ def test_config5_full_size_with_digests(eng):
     assert np.array_equal(dig, digests[first:first + (1 << 20)])
     _, ofin, _, _ = orc.simulate(first, 1 << 9, 10000, want_traj=False, n_threads=CORES)
     assert np.array_equal(fin[:1 << 9], ofin)
+
+
+def test_north_star_2p52_problems_three_decompositions_agree(eng):
+    """The bench's regime (2^48 problems per call, a cascade of cube passes): 2^52 problems as 16 calls of 2^48, as 64
+    calls of 2^46 and as ragged calls -- different blocks, different relevant-digit sets and level structures, the
+    same exact table; every problem accounted for.  (tools/full_space.py does the same over all 2^64.)"""
+    cfg = parse_input_text(synth.north_star_yaml(), 4096, Mode.ATTRACT)
+    net, space = compile_problem(cfg)
+    eng.set_problem(net, space)
+    base, total = 0xABC << 52, 1 << 52
+
+    def sweep(pieces):
+        tables, none, steps, at = [], 0, 0, base
+        for n in pieces:
+            r = eng.attract(at, n, 4096)
+            assert int(r.table['count'].sum()) + r.n_no_attractor == n
+            tables.append(r.table); none += r.n_no_attractor; steps += r.stats['state_steps']; at += n
+        assert at == base + total
+        return merged_rows(tables), none, steps
+
+    a = sweep([1 << 48] * 16)
+    b = sweep([1 << 46] * 64)
+    ragged, sizes = [], [(1 << 48) - 12345, (1 << 47) + 999, 1 << 48, (1 << 46) + 77, (1 << 48) - 1]
+    while sum(ragged) < total:
+        ragged.append(min(sizes[len(ragged) % len(sizes)], total - sum(ragged)))
+    assert all(0 < n <= 1 << 48 for n in ragged) and sum(ragged) == total
+    c = sweep(ragged)
+    assert a == b == c
+    assert sum(r[2] for r in a[0]) + a[1] == total
+    os.environ['BSX_CUBE_DEPTH'] = '1'              # ... and the first-update-only cube pass on a quarter of the first block
+    try:
+        d1 = eng.attract(base, 1 << 42, 4096)
+    finally:
+        os.environ.pop('BSX_CUBE_DEPTH')
+    d8 = eng.attract(base, 1 << 42, 4096)
+    assert rows(d1.table) == rows(d8.table) and d1.stats['state_steps'] == d8.stats['state_steps']
