@@ -87,8 +87,12 @@ def main():
         running.append(r.table)
         return r
 
+    warm = []
     for s in range(args.warmup):
-        step(s, [])
+        step(s, warm)
+    if comm.world > 1 and warm:
+        # the collective's first call sets up its connections: part of the warm-up, like the first launches
+        comm.allgather_records(table_from_merged(merge_tables(warm), _lib.ATTR_REC))
 
     comm.barrier()
     eng.synchronize()
