@@ -1163,8 +1163,8 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         if (h->d_strag.n < list_cap * rec_words) HIPCHK(h, h->d_strag.alloc(list_cap * rec_words));
         const uint32_t fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
 
-        // ---- levels: rel_mask[d - 1] = digits F^d depends on.  The top level is the shallowest one with the
-        // fewest digits (a deeper one would only add updates); BSX_CUBE_DEPTH caps it (1 = first update only).
+        // ---- levels: rel_mask[d - 1] = digits F^d depends on.  The top level is the depth with the fewest digits (the
+        // shallowest such: a deeper one would only add updates); BSX_CUBE_DEPTH caps it (1 = first update only) ...
         uint32_t max_depth = 8;
         if (const char* e = std::getenv("BSX_CUBE_DEPTH")) max_depth = (uint32_t)std::max(1, std::min(16, std::atoi(e)));
         if (h->cube_depth_cap) max_depth = std::min(max_depth, h->cube_depth_cap);
@@ -1174,9 +1174,19 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
         max_depth = std::max(1u, std::min(max_depth, fast_steps > 1 ? fast_steps - 1 : 1u));
         std::vector<uint64_t> rel_mask;
         cube_levels(h, c1, max_depth, rel_mask);
+        // ... unless the block is so small that the extra launches cost more than the updates they save: estimate
+        // 45 us for the first launch, half of that for each level below (not all of them find classes to run), and
+        // 2.4e11 class updates per second (tools/depth_survey.py: blocks with under 2^20 depth-1 classes were up to
+        // 3x slower through four levels than through one)
+        // (an explicit BSX_CUBE_DEPTH keeps the plain rule: tests force levels onto small spaces with it)
+        const bool forced_depth = std::getenv("BSX_CUBE_DEPTH") != nullptr;
         uint32_t top = 1;
-        for (uint32_t d = 2; d <= max_depth; ++d)
-            if (__builtin_popcountll(rel_mask[d - 1]) < __builtin_popcountll(rel_mask[top - 1])) top = d;
+        double best = 0;
+        for (uint32_t d = 1; d <= max_depth; ++d) {
+            const int r_d = __builtin_popcountll(rel_mask[d - 1]);
+            const double est = forced_depth ? (double)r_d : 45.0 * (1.0 + 0.5 * (d - 1)) + std::ldexp(1.0, r_d) * (d + 0.3) / 2.4e5;
+            if (d == 1 || est < best) { best = est; top = d; }
+        }
         auto level_cube = [&](uint64_t digits, bool ordered, Cube& lc) -> int {
             lc = c1;
             lc.rel.clear();
