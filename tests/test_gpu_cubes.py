@@ -284,3 +284,32 @@ def test_deep_levels_equal_plain_enumeration_on_random_spaces(eng, seed):
     assert rows(a.table) == rows(b.table), text
     assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
     assert int(a.table['count'].sum()) + a.n_no_attractor == count
+
+
+@pytest.mark.parametrize('depth', ['2', '8'])
+@pytest.mark.parametrize('name,text,bits,log2n', [('config3', synth.config3_yaml(), 32, 22), ('n128_k2', synth.network_yaml(128, 2, 129), 128, 22),
+                                                  ('n200_k2', synth.network_yaml(200, 2, 2001), 200, 20),
+                                                  ('n48_k3', synth.network_yaml(48, 3, 481), 48, 18)],
+                         ids=['config3', 'n128_k2', 'n200_k2', 'n48_k3'])
+def test_forced_levels_vs_oracle_other_word_counts(eng, name, text, bits, log2n, depth):
+    """The level passes on states of 1, 4 and 8 words (the engine's own choice keeps blocks this small at one level)."""
+    os.environ['BSX_CUBE_DEPTH'] = depth
+    net, space = setup(eng, text)
+    same_as_oracle(eng, net, space, 0, 1 << log2n)
+    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << (log2n - 1)) + 99)
+
+
+@pytest.mark.parametrize('depth', ['2', '8'])
+def test_forced_levels_with_a_warm_up(eng, depth):
+    """Warm-up under the origin's perturbation schedule: one pass at the best depth <= T_p, nothing listed."""
+    os.environ['BSX_CUBE_DEPTH'] = depth
+    text = synth.network_yaml(40, 2, 401, perturbations={3: {'1': '1-3'}, 17: {'0': '2, 5'}}, fixed={9: '1'})
+    for max_t in (4096, 12):
+        net, space = setup(eng, text, max_t)
+        same_as_oracle(eng, net, space, 0, 1 << 22, max_t=max_t)
+        same_as_oracle(eng, net, space, (1 << 30) + 777, (1 << 21) + 5, max_t=max_t)
+    net, space = setup(eng, open(os.path.join(os.path.dirname(__file__), 'golden', 'cambium2.yaml')).read(), np.inf)
+    got = eng.attract(0, 1 << 30)
+    os.environ['BSX_CUBES'] = '0'
+    plain = eng.attract(0, 1 << 30)
+    assert len(got.table) == 39 and rows(got.table) == rows(plain.table) and got.stats['state_steps'] == plain.stats['state_steps']
