@@ -183,21 +183,22 @@ struct AttractParams {
     // fresh stage makes `cube_depth` updates before the first lookup, and a class whose common state F^depth(x)
     // is a cached cycle state -- its members enter the cycle at different times <= depth -- is not accounted but
     // listed by its representative's initial state: workgroup g appends to its own segment near[g * near_cap ..]
-    // (near_cap states of nw words, no global atomics) and leaves its count in near_counts[g]; k_compact_near
-    // then packs the segments into one list.  Counters::near_classes = the total, near_overflow = a segment was
-    // too small.  The host runs the listed classes again one level down:
+    // (near_cap states of nw words, a counter in LDS, no global atomics) and leaves its count in near_counts[g];
+    // k_compact_near then packs the segments into one list.  Counters::near_classes = the total, near_overflow =
+    // a segment was too small.  The host runs the listed classes again one level down:
     // entries != null: work item i is sub-assignment i & (2^entry_shift - 1) of the digits this level adds,
     // on top of the state entries[(i >> entry_shift) * nw ..].
-    uint64_t chunk_first;       // pool kernel: wave w of the grid starts with [w * chunk_first, (w + 1) * chunk_first); the
-                                // shared cursor hands out what lies beyond n_waves * chunk_first.  Same-address atomics
-                                // complete at some 15 ns apiece however many waves wait, so a pass must not take
-                                // more than a few hundred of them per 100 us: small passes are split evenly up front.
     uint32_t cube_depth;        // >= 1 (1 = one update, then lookups: the plain cube pass)
     uint32_t entry_shift;
     const uint32_t* entries;
     uint32_t* near;
     uint32_t* near_counts;
     uint64_t near_cap;
+    // Work distribution of the pool kernel: wave w of the grid starts with [w * chunk_first, (w + 1) * chunk_first);
+    // the shared cursor hands out what lies beyond n_waves * chunk_first, `chunk` at a time (chunk == 0: nothing
+    // lies beyond).  Same-address atomics complete at some 15 ns apiece however many waves wait, so a pass must
+    // not take more than a few hundred of them per 100 us: small cube passes are split evenly up front.
+    uint64_t chunk_first;
     // general kernel, discovery from explicit states: work item i starts at states[i * nw ..] (no enumeration)
     const uint32_t* states;
 };
