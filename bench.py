@@ -71,7 +71,24 @@ def main():
     from boolsi_amd.engine import Engine
     # BSX_BENCH_DEVICE: rehearse several ranks on one GPU (with BSX_DIST_BACKEND=socket); normally rank = GPU
     eng = Engine(int(os.environ.get('BSX_BENCH_DEVICE', comm.local_rank)))
-    comm.attach_engine(eng)         # RCCL communicator on the engine's device (N > 1)
+    # RCCL communicator on the engine's device (N > 1).  This is a measurement harness: if RCCL cannot be set up on
+    # this node the final merge goes over the TCP control plane instead, and the line says so (`config.merge`).
+    rccl_problem = None
+
+    def agree_on_data_plane(err):
+        nonlocal rccl_problem
+        errs = [e for e in comm.allgather_obj(err) if e]
+        if errs and comm.backend == 'rccl':
+            comm.backend = 'socket'
+            rccl_problem = errs[0]
+
+    if comm.world > 1:
+        err = None
+        try:
+            comm.attach_engine(eng)
+        except Exception as e:      # noqa: BLE001
+            err = '{}: {}'.format(type(e).__name__, str(e)[:200])
+        agree_on_data_plane(err)
 
     cfg = parse_input_text(synth.north_star_yaml(), MAX_T, Mode.ATTRACT)
     net, space = compile_problem(cfg)
@@ -92,7 +109,12 @@ def main():
         step(s, warm)
     if comm.world > 1 and warm:
         # the collective's first call sets up its connections: part of the warm-up, like the first launches
-        comm.allgather_records(table_from_merged(merge_tables(warm), _lib.ATTR_REC))
+        err = None
+        try:
+            comm.allgather_records(table_from_merged(merge_tables(warm), _lib.ATTR_REC))
+        except Exception as e:      # noqa: BLE001
+            err = '{}: {}'.format(type(e).__name__, str(e)[:200])
+        agree_on_data_plane(err)
 
     comm.barrier()
     eng.synchronize()
@@ -149,7 +171,8 @@ def main():
                                    '-t 4096, 2^{} consecutive problem indices per GPU per step'.format(args.log2_batch),
                        'n_nodes': n, 'problems_per_gpu_per_step': batch, 'max_t': MAX_T,
                        'partition': 'range x{}'.format(comm.world),
-                       'merge': ('one all-gather after the last step, data plane: ' + str(comm.backend)) if comm.world > 1 else 'none (1 GPU)'},
+                       'merge': ('one all-gather after the last step, data plane: ' + str(comm.backend) +
+                                 (' (RCCL could not be used: ' + rccl_problem + ')' if rccl_problem else '')) if comm.world > 1 else 'none (1 GPU)'},
             'value_counts': 'executed network updates x n nodes (work skipped by the cycle cache / class pooling is not counted)',
             'attractors_per_s': problems / elapsed,
             'executed_node_updates_per_s': tot_exec * n / elapsed,
