@@ -1291,6 +1291,10 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                         it = pass_table.emplace(key, rec_a).first;
                     }
                     bsx_attr_rec& e = it->second;
+                    // (a class of up to 2^48 members that a very long transient leads to: the ABI's 64-bit sum of l must hold it)
+                    const unsigned __int128 wl = (unsigned __int128)m * traj;
+                    if ((wl >> 63) != 0 || e.sum_l + (uint64_t)wl < e.sum_l)
+                        return fail(h, BSX_ERR_UNSUPPORTED, "sum of trajectory lengths of an attractor exceeds 64 bits: split the range into smaller calls");
                     e.count += m;
                     e.sum_l += m * traj;
                     const unsigned __int128 sq = (unsigned __int128)(m * traj) * traj + e.sum_l2_lo;
