@@ -356,6 +356,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     h->fast_ok = true;
     h->cube_depth_cap = 0;
     h->life_valid = 0;
+    h->image_n = ~size_t(0);
     h->h_journal.clear();
     h->journal_stale = true;
     h->fast_steps = 0;
@@ -594,6 +595,22 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
         HIPCHK(h, h->d_near_counts.reserve(L.grid.x));
         P.near = h->d_near_seg.p;
         P.near_counts = h->d_near_counts.p;
+    }
+    if (kind == kPassPool && !(std::getenv("BSX_MIRROR_IMAGE") && std::getenv("BSX_MIRROR_IMAGE")[0] == '0')) {
+        // the cache mirror as an image: rebuilt (one workgroup) only when the journal or the mirror size has changed
+        const size_t words = 4 + (size_t)P.cc.lds_slots * (h->cache_stride / 4);
+        if (h->image_n != h->h_journal.size() || h->image_slots != P.cc.lds_slots || h->d_mirror.n < words) {
+            HIPCHK(h, h->d_mirror.reserve(words));
+            AttractParams B = P;
+            B.count = 0;
+            B.mirror_image = nullptr;
+            B.mirror_out = h->d_mirror.p;
+            HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, dim3(1), shmem, h->stream, B));
+            h->image_n = h->h_journal.size();
+            h->image_slots = P.cc.lds_slots;
+        }
+        P.mirror_image = h->d_mirror.p;
+        P.mirror_out = nullptr;
     }
     const double pt1 = now_ms();
     HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));

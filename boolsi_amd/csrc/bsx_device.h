@@ -199,6 +199,12 @@ struct AttractParams {
     // lies beyond).  Same-address atomics complete at some 15 ns apiece however many waves wait, so a pass must
     // not take more than a few hundred of them per 100 us: small cube passes are split evenly up front.
     uint64_t chunk_first;
+    // Pool kernel: the LDS cache mirror (header + lds_slots entries) as a ready-made image.  Regenerating the cached
+    // cycles from the journal is serial work of one thread per workgroup (8 us for 32 cycle states, far more for a
+    // few hundred) that every launch of a cascade repeated; the image is built once per journal state by a
+    // one-workgroup launch with mirror_out set (which does nothing else) and copied by all threads afterwards.
+    const uint32_t* mirror_image;
+    uint32_t* mirror_out;
     // general kernel, discovery from explicit states: work item i starts at states[i * nw ..] (no enumeration)
     const uint32_t* states;
 };

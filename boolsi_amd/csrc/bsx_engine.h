@@ -76,6 +76,9 @@ struct bsx_engine {
     uint64_t table_slots = 0;
     bool table_dirty = false;
     bsx::DevBuf<uint32_t> d_strag;
+    bsx::DevBuf<uint32_t> d_mirror;     // pool kernel: image of the LDS cache mirror, valid for (image_n journal records, image_slots slots)
+    size_t image_n = ~size_t(0);
+    uint32_t image_slots = 0;
     bsx::DevBuf<uint32_t> d_near_seg;   // deep cube passes: classes listed for the level below, one segment per workgroup,
     bsx::DevBuf<uint32_t> d_near_counts;    // the segments' fill counts,
     bsx::DevBuf<uint32_t> d_near_list;  // and the packed list the next level reads

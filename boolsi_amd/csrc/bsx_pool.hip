@@ -117,15 +117,21 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
     for (int w = 0; w < NW; ++w) { fm0[w] = P.sp.fixmask[w]; fv0[w] = P.sp.fixval[w]; any_fixed |= fm0[w]; }
     const bool has_fixed = any_fixed != 0;                  // uniform
-    for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0;
+    const uint32_t* const image = P.mirror_image;           // uniform: the mirror as built by an earlier launch (bsx_device.h)
+    if (image) { for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = image[i]; }
+    else { for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0; }
     for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl2h[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
     dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (!image && threadIdx.x == 0) {
         uint32_t seen = 0, n_states = 0, n_attr = 0;
         cache_pull<NW, K>(P.cc, nv, fm0, fv0, lc, seen, n_states, n_attr, kAccs);
     }
     __syncthreads();
+    if (P.mirror_out) {                                     // uniform: this launch only builds the image
+        for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) P.mirror_out[i] = lc[i];
+        return;
+    }
     const uint32_t* cbase = lc + kCacheHeaderWords;
     for (uint32_t sl = threadIdx.x; sl < P.cc.lds_slots; sl += blockDim.x) {
         const uint32_t tg = cbase[sl * S + NW] & kTagMask;
