@@ -31,7 +31,7 @@ hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t sh
 hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
 size_t pool_extra_bytes(uint32_t nw);
 hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
-hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw, uint32_t* out, hipStream_t stream);
+hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw, uint32_t* out, uint32_t* zero, uint32_t zero_words, hipStream_t stream);
 hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, const DevSpace& sp,
                           uint64_t n_states, uint32_t* succ, uint32_t warm_steps);
 hipError_t launch_fg_double(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t cus, hipStream_t st);
@@ -613,7 +613,8 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
         P.mirror_out = nullptr;
     }
     const double pt1 = now_ms();
-    HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+    if (h->ctr_zeroed) h->ctr_zeroed = false;               // (k_compact_near of the pass before has cleared them)
+    else HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (kind == kPassPool) HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
     else if (kind == kPassLean) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
@@ -628,7 +629,10 @@ int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>
     g_prof[0] += pt1 - pt0; g_prof[1] += pt2 - pt1; g_prof[2] += pt3 - pt2; g_prof[3] += run.ms;
     if (lists && run.ctr.near_classes && !run.ctr.near_overflow) {
         HIPCHK(h, h->d_near_list.reserve((size_t)run.ctr.near_classes * h->net.nw));
-        HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, L.grid.x, P.near_cap, h->net.nw, h->d_near_list.p, h->stream));
+        static_assert(sizeof(Counters) % 4 == 0, "cleared word by word");
+        HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, L.grid.x, P.near_cap, h->net.nw, h->d_near_list.p,
+                                      reinterpret_cast<uint32_t*>(h->d_ctr.p), (uint32_t)(sizeof(Counters) / 4), h->stream));
+        h->ctr_zeroed = true;
     }
     if (std::getenv("BSX_DEBUG"))
         std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu stragglers, %.3f ms (BSX_DIAG build: %llu wave iterations, %llu service rounds)\n",
@@ -942,6 +946,7 @@ extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t co
                                uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
                                uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats) {
     if (!h) return BSX_ERR_INVALID;
+    h->ctr_zeroed = false;      // (whatever an earlier call left behind: other entry points use the counters too)
     if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
     if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
     if (int rc = check_range(h, first, count)) return rc;

@@ -76,7 +76,7 @@ struct ProblemRec32 {           // per-problem output, device layout
     uint32_t pad;
 };
 
-struct Counters {               // zeroed before every launch
+struct alignas(256) Counters {   // zeroed before every launch (a multiple of 256 bytes: one fill kernel, not two)
     unsigned long long cursor;          // next chunk of problems
     unsigned long long steps_ref;       // reference-equivalent steps
     unsigned long long steps_exec;      // executed network updates

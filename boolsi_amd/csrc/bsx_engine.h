@@ -105,6 +105,7 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
 
     bsx::DevBuf<bsx::Counters> d_ctr;
+    bool ctr_zeroed = false;            // d_ctr has been cleared on the device already (by k_compact_near): the next pass skips its memset
     bsx::Counters* h_ctr = nullptr;     // pinned landing buffer for the counters of a pass
 
     // functional-graph mode (bsx_fgraph.hip): N-sized arrays, kept between calls (grow-only)

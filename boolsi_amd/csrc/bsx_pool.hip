@@ -723,7 +723,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 // Deep cube passes: the workgroups' segments of listed classes -> one contiguous list (block g copies segment g
 // to where the segments before it end).
 __global__ __launch_bounds__(256) void k_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg,
-                                                      uint64_t cap, uint32_t nw, uint32_t* out) {
+                                                      uint64_t cap, uint32_t nw, uint32_t* out, uint32_t* zero, uint32_t zero_words) {
+    // (block 0 also clears the counters for the next pass -- the host has read them -- which saves that pass its memset)
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0;
     __shared__ unsigned long long before;
     if (threadIdx.x == 0) before = 0;
     __syncthreads();
@@ -739,9 +741,9 @@ __global__ __launch_bounds__(256) void k_compact_near(const uint32_t* seg, const
 }
 
 hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw,
-                               uint32_t* out, hipStream_t stream) {
-    if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_compact_near, dim3(n_seg), dim3(256), 0, stream, seg, counts, n_seg, cap, nw, out);
+                               uint32_t* out, uint32_t* zero, uint32_t zero_words, hipStream_t stream) {
+    if (!n_seg) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_compact_near, dim3(n_seg), dim3(256), 0, stream, seg, counts, n_seg, cap, nw, out, zero, zero_words);
     return hipGetLastError();
 }
 
