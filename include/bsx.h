@@ -137,7 +137,10 @@ int  bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_words,
 
 /* attract (attract.py:262-302 semantics for every problem of [first, first + count)):
  * aggregated table (unordered) into table[0..*n_out), problems without attractor counted in
- * *n_no_attractor.  per_problem (count entries) may be NULL. */
+ * *n_no_attractor.  per_problem (count entries) may be NULL.
+ * count <= 2^48 per call (a record's 64-bit sum of trajectory lengths must hold count x length; BSX_ERR_INVALID
+ * beyond), <= 2^32 with per_problem.  Large aligned ranges are not enumerated problem by problem: the engine
+ * steps classes of problems that provably share their trajectory from some update on (DESIGN.md "Cube collapse"). */
 int  bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count,
                      uint64_t max_t, uint64_t max_len,
                      bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
