@@ -4,13 +4,14 @@ Headline benchmark (BASELINE.json): node-state-updates/s + attractors/s of an `a
 a synthetic 64-node network (K = 2, seed 64, every node 'any'; the 2^64 space is capped to an
 index range), at 1/2/4/8 GPUs.
 
-One "step" = one pass of the hot path (bsx_run_attract: enumerate -> step -> detect -> aggregate)
-over one batch of 2^LOG2_BATCH consecutive problem indices per GPU (default 2^48, the most one call takes),
-folded into the rank's running attractor table.  The engine runs such a batch as a cascade of cube passes
-(DESIGN.md "Deeper collapse"): a few launches of k_attract_pool per step, the first one dominant.  Weak scaling: every rank gets its own batch each step.  After the LAST step the
-per-rank tables are merged with one RCCL all-gather (inside the timed region; N > 1 only).  Network
-tables live in HBM before the timed region; initial states are generated on the device from the
-index, so nothing crosses PCIe inside a step except the (< 1 MB) attractor log.
+One "step" = one pass of the hot path (bsx_run_attract2: enumerate -> step -> detect -> aggregate) over one batch of
+2^LOG2_BATCH consecutive problem indices per GPU (default 2^56: 1/256 of the whole space), folded into the rank's running
+attractor table.  The engine runs such a batch as ONE chain of launches (DESIGN.md "Deeper collapse" / "levels chained on
+the device"): k_attract_pool per level of the cube cascade with a packing kernel in between, the top level dominant; the
+host enqueues the chain, waits once and adds up wide integers.  Weak scaling: every rank gets its own batch each step.
+After the LAST step the per-rank tables are merged with one RCCL all-gather (inside the timed region; N > 1 only).
+Network tables live in HBM before the timed region; initial states are generated on the device from the index, so
+nothing crosses PCIe inside a step except a few KB of counters.
 
 Accounting (what each number counts):
   value / executed_node_updates_per_s   network updates the kernels really EXECUTED x n nodes / s.
@@ -20,13 +21,15 @@ Accounting (what each number counts):
   reference_equivalent_node_updates_per_s   n x (sum of the reference loop's stop times, model.py:201) / s:
                                         what a stepping implementation would have had to do.
   attractors_per_s                      problems resolved per second (BASELINE.json's second metric).
-  roofline                              SURVEY 8(d) basis: 0.25 B per EXECUTED node update, per launch of the
-                                        dominant kernel (averaged over its launches, all levels of the cascade)
-                                        / its HIP-event duration, vs 8 TB/s.  <= 1 by
-                                        construction.  The kernel keeps states in registers/LDS, so its real
-                                        HBM traffic (`traffic`, from a separate PMC pass) is ~1e-4 of that and
-                                        HBM is not what limits it: `issue_bound` gives what the PMC counters show
-                                        (VALU, SALU and LDS busy fractions), from the profile named in its `source`.
+  roofline                              what bounds the dominant kernel (the top-level k_attract_pool launch of every step):
+                                        `bound` names the busiest unit of the PMC profile of THIS build (profiles/r03_pmc.json:
+                                        VALU issue / LDS pipeline / SALU issue), `achieved` = that unit's instructions per
+                                        second = its per-executed-update cost from the profile x the updates this run's
+                                        dominant launches executed / their HIP-event duration (measured live), `peak` =
+                                        1 instruction per cycle per SIMD (VALU, SALU) or per CU (LDS).
+                                        `hbm_normalised`: SURVEY 8(d)'s figure, 0.25 B per EXECUTED node update / launch time
+                                        vs 8 TB/s -- a normalised rate, not HBM utilisation: states stay in registers / LDS,
+                                        the measured HBM traffic (`traffic`) is orders of magnitude below it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch B]
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); this program itself
@@ -44,7 +47,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_NODE_UPDATE = 0.25    # read + write of the n-bit state per step = n/4 B
 MAX_T = 4096
-PMC_FILE = os.path.join('profiles', 'r02_pmc.json')     # written by tools/pmc_read.py from the --pmc passes
+PMC_FILE = os.path.join('profiles', 'r03_pmc.json')     # written by tools/pmc_read.py from the --pmc passes
 
 
 def main():
@@ -52,13 +55,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--log2-batch', type=int, default=48, help='log2 of problems per GPU per step')
+    ap.add_argument('--log2-batch', type=int, default=56, help='log2 of problems per GPU per step (<= 63)')
+    ap.add_argument('--allow-socket-merge', action='store_true', help='N > 1: if RCCL cannot be set up, merge over the TCP control plane instead of failing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-log2-sample', type=int, default=25, help='log2 of the problems the CPU baseline runs (2^25: ~12 s on the box)')
     args = ap.parse_args()
 
     from boolsi_amd import synth, _lib
-    from boolsi_amd.attract import merge_tables, table_from_merged
+    from boolsi_amd.attract import merge_tables, record_ints, table_from_merged
     from boolsi_amd.compile import compile_problem
     from boolsi_amd.constants import Mode
     from boolsi_amd.dist import Comm
@@ -71,14 +75,19 @@ def main():
     from boolsi_amd.engine import Engine
     # BSX_BENCH_DEVICE: rehearse several ranks on one GPU (with BSX_DIST_BACKEND=socket); normally rank = GPU
     eng = Engine(int(os.environ.get('BSX_BENCH_DEVICE', comm.local_rank)))
-    # RCCL communicator on the engine's device (N > 1).  This is a measurement harness: if RCCL cannot be set up on
-    # this node the final merge goes over the TCP control plane instead, and the line says so (`config.merge`).
+    # RCCL communicator on the engine's device (N > 1).  A node whose RCCL cannot be set up fails the run (non-zero exit on
+    # every rank) unless the socket data plane was asked for: BSX_DIST_BACKEND=socket, or --allow-socket-merge to downgrade
+    # after a failed attempt -- the line then says so in `config.merge`.
     rccl_problem = None
 
     def agree_on_data_plane(err):
         nonlocal rccl_problem
         errs = [e for e in comm.allgather_obj(err) if e]
         if errs and comm.backend == 'rccl':
+            if not args.allow_socket_merge:
+                comm.abort()
+                raise SystemExit('RCCL could not be set up ({}); rerun with --allow-socket-merge or BSX_DIST_BACKEND=socket '
+                                 'to merge over TCP instead'.format(errs[0]))
             comm.backend = 'socket'
             rccl_problem = errs[0]
 
@@ -94,15 +103,25 @@ def main():
     net, space = compile_problem(cfg)
     eng.set_problem(net, space)
     n = net.n_nodes
+    info = eng.network_info()
     batch = 1 << args.log2_batch
+    n_batches = (1 << 64) // batch
     base = 0x0123456789ABCDEF & ~(batch - 1)     # somewhere inside the 2^64 space, batch aligned
+    if (args.warmup + args.steps) * comm.world > n_batches:
+        raise SystemExit('2^64 / 2^{} = {} batches do not cover {} steps x {} ranks: lower --log2-batch'.format(
+            args.log2_batch, n_batches, args.warmup + args.steps, comm.world))
 
     def step(s, running):
-        first = base + (s * comm.world + comm.rank) * batch
-        r = eng.attract(first, batch, MAX_T)
-        assert int(r.table['count'].sum()) + r.n_no_attractor == batch      # every problem accounted for
-        running.append(r.table)
+        first = (base + (s * comm.world + comm.rank) * batch) % (1 << 64)
+        r = eng.attract2(first, batch, MAX_T)
+        running.append(r)
         return r
+
+    def checked(results):
+        """every problem of every step accounted for (exact, wide); -> the step tables"""
+        for r in results:
+            assert sum(record_ints(a)[2] for a in r.table) + r.n_no_attractor == batch
+        return [r.table for r in results]
 
     warm = []
     for s in range(args.warmup):
@@ -111,7 +130,7 @@ def main():
         # the collective's first call sets up its connections: part of the warm-up, like the first launches
         err = None
         try:
-            comm.allgather_records(table_from_merged(merge_tables(warm), _lib.ATTR_REC))
+            comm.allgather_records(table_from_merged(merge_tables(checked(warm)), _lib.ATTR_REC2))
         except Exception as e:      # noqa: BLE001
             err = '{}: {}'.format(type(e).__name__, str(e)[:200])
         agree_on_data_plane(err)
@@ -119,19 +138,22 @@ def main():
     comm.barrier()
     eng.synchronize()
     t0 = time.perf_counter()
-    steps_ref = steps_exec = 0
-    kernel_ms = 0.0
-    launches = 0
-    tables = []
+    steps_ref = steps_exec = dom_exec = dom_launches = launches = syncs = 0
+    kernel_ms = dom_ms = 0.0
+    results = []
     for s in range(args.warmup, args.warmup + args.steps):
-        r = step(s, tables)
-        steps_ref += r.stats['state_steps']
-        steps_exec += r.stats['executed_steps']
-        kernel_ms += r.stats['kernel_ms']
-        launches += r.stats['kernel_launches']
-    mine = merge_tables(tables)
+        st = step(s, results).stats
+        steps_ref += st['state_steps']
+        steps_exec += st['executed_steps']
+        kernel_ms += st['kernel_ms']
+        launches += st['kernel_launches']
+        dom_ms += st['dominant_ms']
+        dom_exec += st['dominant_executed_steps']
+        dom_launches += st['dominant_launches']
+        syncs += st['host_syncs']
+    mine = merge_tables(checked(results))
     # the job's one data collective: per-rank tables -> every rank (RCCL all-gather over xGMI)
-    merged = merge_tables(comm.allgather_records(table_from_merged(mine, _lib.ATTR_REC))) if comm.world > 1 else mine
+    merged = merge_tables(comm.allgather_records(table_from_merged(mine, _lib.ATTR_REC2))) if comm.world > 1 else mine
     eng.synchronize()
     comm.barrier()
     elapsed = comm.allreduce_max(time.perf_counter() - t0)
@@ -140,20 +162,46 @@ def main():
     if comm.rank == 0:
         problems = batch * args.steps * comm.world
         assert sum(e[1] for e in merged.values()) <= problems
-        # roofline of the dominant kernel (k_attract_pool), rank 0: executed algorithmic bytes per launch / avg duration
-        avg_launch_s = kernel_ms / 1e3 / launches
-        alg_bytes_per_launch = steps_exec / launches * n * BYTES_PER_NODE_UPDATE
-        achieved = alg_bytes_per_launch / avg_launch_s / 1e9
-        traffic = traffic_source = None
-        issue = None
+        # roofline of the dominant kernel (the top-level k_attract_pool launch of every step), rank 0, measured live:
+        # HIP events around those launches, the updates they executed from their own counters
+        kernel = 'k_attract_pool<{},{},{},true>'.format(info['state_words32'], info['mux_slots'], info['lut_mode'])
+        avg_launch_s = dom_ms / 1e3 / dom_launches
+        upd_per_launch = dom_exec / dom_launches
+        alg_bytes_per_launch = upd_per_launch * n * BYTES_PER_NODE_UPDATE
+        hbm_norm = alg_bytes_per_launch / avg_launch_s / 1e9
+        roof = {'bound': 'hbm-normalised', 'achieved': hbm_norm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_norm / HBM_PEAK_GBS,
+                'traffic': None, 'note': 'no PMC profile of this build at ' + PMC_FILE + ': only the normalised figure'}
         ppath = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(ppath):
             with open(ppath) as f:
                 pmc = json.load(f)
-            if pmc.get('log2_batch') == args.log2_batch:
-                traffic = pmc.get('hbm_bytes_per_launch')
-                traffic_source = PMC_FILE + ' (separate rocprofv3 --pmc passes of this command, not measured in this run)'
-                issue = dict(pmc.get('issue_bound') or {}, source=PMC_FILE)
+            per_upd = pmc.get('per_executed_update') or {}
+            if pmc.get('log2_batch') == args.log2_batch and per_upd:
+                units = {'valu': ('valu_insts', 1024), 'salu': ('salu_insts', 1024), 'lds': ('lds_busy_cycles', 256)}
+                clock_hz = pmc.get('shader_clock_hz', 2.4e9)
+                rates = {}
+                for unit, (key, lanes) in units.items():
+                    if key in per_upd:
+                        ach = per_upd[key] * upd_per_launch / avg_launch_s
+                        rates[unit] = (ach, lanes * clock_hz)
+                if rates:
+                    unit = max(rates, key=lambda u: rates[u][0] / rates[u][1])
+                    ach, peak = rates[unit]
+                    roof = {'bound': {'valu': 'valu-issue', 'salu': 'salu-issue', 'lds': 'lds-pipeline'}[unit],
+                            'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'Ginst/s' if unit != 'lds' else 'Gcycle/s',
+                            'frac': ach / peak,
+                            'traffic': pmc.get('hbm_bytes_per_launch'),
+                            'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc passes of this command, not measured in this run)',
+                            'all_units_frac': {u: r[0] / r[1] for u, r in rates.items()},
+                            'basis': 'instructions (LDS: busy cycles) per executed update from the PMC passes of this build x updates the '
+                                     'dominant launches executed in THIS run / their HIP-event duration; peak = units x shader clock',
+                            'pmc_busy_fractions': pmc.get('issue_bound'), 'source': PMC_FILE}
+        roof.update({'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3, 'launches_timed': dom_launches,
+                     'executed_updates_per_launch': upd_per_launch,
+                     'hbm_normalised': {'achieved': hbm_norm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_norm / HBM_PEAK_GBS,
+                                        'alg_bytes_per_launch': alg_bytes_per_launch,
+                                        'basis': '0.25 B per EXECUTED node update (SURVEY 8d) x executed updates per launch / HIP-event '
+                                                 'launch time: a normalised rate, states stay in registers / LDS'}})
         out = {
             'metric': 'node-state-updates/s',
             'value': tot_exec * n / elapsed,
@@ -168,7 +216,7 @@ def main():
             'dtype': 'u32',
             'data': 'synthetic',
             'config': {'workload': 'north-star attract sweep: synthetic n=64 K=2 seed=64, all nodes any, '
-                                   '-t 4096, 2^{} consecutive problem indices per GPU per step'.format(args.log2_batch),
+                                   '-t 4096, 2^{} consecutive problem indices per GPU per step (one bsx_run_attract2 call)'.format(args.log2_batch),
                        'n_nodes': n, 'problems_per_gpu_per_step': batch, 'max_t': MAX_T,
                        'partition': 'range x{}'.format(comm.world),
                        'merge': ('one all-gather after the last step, data plane: ' + str(comm.backend) +
@@ -180,13 +228,11 @@ def main():
             'executed_updates_per_problem': tot_exec / problems,
             'state_steps_per_problem': tot_ref / problems,
             'n_attractors': len(merged),
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel': 'k_attract_pool<NW=2,K=2,LDS>', 'avg_launch_ms': avg_launch_s * 1e3,
-                         'alg_bytes_per_launch': alg_bytes_per_launch,
-                         'basis': '0.25 B per EXECUTED node update (SURVEY 8d) x executed updates per launch / HIP-event '
-                                  'launch time; states stay in registers/LDS, so this is a normalised rate, not HBM utilisation',
-                         'issue_bound': issue},
+            'kernel_ms_per_step': kernel_ms / args.steps,
+            'host_ms_per_step': elapsed * 1e3 / args.steps - kernel_ms / args.steps,
+            'kernel_launches_per_step': launches / args.steps,
+            'host_syncs_per_step': syncs / args.steps,
+            'roofline': roof,
         }
         if comm.world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_oracle import Oracle        # timed CPU baseline only (kind "port")

@@ -20,8 +20,6 @@ from .dist import Comm, partition
 from .engine import key_to_int
 from .model import decode_state
 
-MAX_TILE = 1 << 48      # problems per engine call: ranges that collapse into cubes
-PLAIN_TILE = 1 << 32    # ... and the limit for those that do not
 
 
 class AggregatedAttractor:
@@ -45,56 +43,82 @@ class AggregatedAttractor:
         return (self.frequency * self.sum_l2 - self.sum_l * self.sum_l) / self.frequency
 
 
+def _words(a):
+    """little-endian 64-bit words (numpy array, list, or a plain int) -> Python int"""
+    if np.ndim(a) == 0:
+        return int(a)
+    v = 0
+    for w, x in enumerate(a):
+        v |= int(x) << (64 * w)
+    return v
+
+
+def record_ints(a):
+    """One bsx_attr_rec / bsx_attr_rec2 (numpy record or dict-like) -> (key, length, count, sum_l, sum_l2) as ints."""
+    names = a.dtype.names if hasattr(a, 'dtype') else a.keys()
+    if 'sum_l2' in names:
+        return key_to_int(a['key']), int(a['length']), _words(a['count']), _words(a['sum_l']), _words(a['sum_l2'])
+    return (key_to_int(a['key']), int(a['length']), int(a['count']), int(a['sum_l']),
+            int(a['sum_l2_lo']) + (int(a['sum_l2_hi']) << 64))
+
+
 def merge_tables(tables):
-    """List of bsx_attr_rec arrays -> dict key(int) -> [length, count, sum_l, sum_l2] (exact ints)."""
+    """List of bsx_attr_rec / bsx_attr_rec2 arrays -> dict key(int) -> [length, count, sum_l, sum_l2] (exact ints)."""
     merged = {}
     for table in tables:
         for a in table:
-            key = key_to_int(a['key'])
+            key, length, count, s1, s2 = record_ints(a)
             e = merged.get(key)
             if e is None:
-                merged[key] = [int(a['length']), int(a['count']), int(a['sum_l']),
-                               int(a['sum_l2_lo']) + (int(a['sum_l2_hi']) << 64)]
+                merged[key] = [length, count, s1, s2]
             else:
-                if e[0] != int(a['length']):
+                if e[0] != length:
                     raise RuntimeError('attractor {} reported with two lengths'.format(key))
-                e[1] += int(a['count'])
-                e[2] += int(a['sum_l'])
-                e[3] += int(a['sum_l2_lo']) + (int(a['sum_l2_hi']) << 64)
+                e[1] += count
+                e[2] += s1
+                e[3] += s2
     return merged
 
 
 def table_from_merged(merged, dtype):
+    """The merged dict as an array of `dtype` records (ATTR_REC: the sums must fit its 64 / 128-bit fields)."""
+    m64 = 0xFFFFFFFFFFFFFFFF
     out = np.zeros(len(merged), dtype)
+    wide = 'sum_l2' in dtype.names
     for i, (key, (length, count, s1, s2)) in enumerate(sorted(merged.items())):
         for w in range(4):
-            out[i]['key'][w] = (key >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
-        out[i]['length'], out[i]['count'], out[i]['sum_l'] = length, count, s1
-        out[i]['sum_l2_lo'], out[i]['sum_l2_hi'] = s2 & 0xFFFFFFFFFFFFFFFF, s2 >> 64
+            out[i]['key'][w] = (key >> (64 * w)) & m64
+        out[i]['length'] = length
+        if wide:
+            for name, v, nwords in (('count', count, 2), ('sum_l', s1, 3), ('sum_l2', s2, 4)):
+                if v >> (64 * nwords):
+                    raise OverflowError('{} does not fit {} bits'.format(name, 64 * nwords))
+                for w in range(nwords):
+                    out[i][name][w] = (v >> (64 * w)) & m64
+        else:
+            if count >> 64 or s1 >> 64 or s2 >> 128:
+                raise OverflowError('sums exceed bsx_attr_rec: use ATTR_REC2')
+            out[i]['count'], out[i]['sum_l'] = count, s1
+            out[i]['sum_l2_lo'], out[i]['sum_l2_hi'] = s2 & m64, s2 >> 64
     return out
 
 
 def run_attract_range(engine, first, count, max_t=inf, max_attractor_l=inf, cap=1 << 20):
-    """Engine over [first, first+count) in tiles -> (merged dict, n_no_attractor, stats dict)."""
+    """Engine over [first, first+count) -> (merged dict, n_no_attractor, stats dict).  ONE engine call however large
+    the range (bsx_run_attract2: 128-bit index and count, wide sums), as one attract_master run covers the
+    reference's whole N (attract.py:67-230); ranges beyond 2^128 problems are cut into calls of 2^127."""
     merged_tables, none = [], 0
     stats = {'problems': 0, 'state_steps': 0, 'executed_steps': 0, 'kernel_ms': 0.0, 'total_ms': 0.0,
              'kernel_launches': 0}
-    from .engine import EngineError
-    done, limit = 0, MAX_TILE
+    done = 0
     while done < count:
-        tile = min(limit, count - done)
-        try:
-            r = engine.attract(first + done, tile, max_t, max_attractor_l, cap=cap)
-        except EngineError as e:
-            if e.status != -4 or limit == PLAIN_TILE:
-                raise
-            limit = PLAIN_TILE      # this space does not collapse: plain enumeration, 2^32 problems at a time
-            continue
+        piece = min(count - done, 1 << 127)
+        r = engine.attract2(first + done, piece, max_t, max_attractor_l, cap=cap)
         merged_tables.append(r.table)
         none += r.n_no_attractor
         for k in stats:
             stats[k] += r.stats[k]
-        done += tile
+        done += piece
     return merge_tables(merged_tables), none, stats
 
 
@@ -121,7 +145,7 @@ def attract_master(engine, origin_simulation_problem, simulation_problem_variati
 
     if comm.active:
         from . import _lib
-        tables = comm.allgather_records(table_from_merged(merged, _lib.ATTR_REC))
+        tables = comm.allgather_records(table_from_merged(merged, _lib.ATTR_REC2))
         merged = merge_tables(tables)
         none, steps, execd = comm.allreduce_sum_int([none, stats['state_steps'], stats['executed_steps']])
         stats['state_steps'], stats['executed_steps'] = steps, execd

@@ -1,0 +1,1301 @@
+// Host side of attract (include/bsx.h: bsx_run_attract, bsx_run_attract2, bsx_run_attract_fgraph): orchestration of
+// the detector / lean / class-pool kernels, the cube analysis and the cascade of cube passes -- enqueued as one chain
+// of launches whose levels hand their lists over on the device -- and the exact, wide-integer merge of the results.
+// No CPU compute path exists here: every problem is resolved by gfx950 kernels (bsx_attract.hip, bsx_lean.hip,
+// bsx_pool_kernel.h, bsx_fgraph.hip); the host only reads truth tables (which digits can matter) and adds up sums.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+#include "bsx_host.h"
+
+using namespace bsx;
+
+namespace {
+
+constexpr uint64_t kFastMinProblems = 8192;     // below this the general kernel alone is used
+constexpr uint64_t kDiscoverySample = 65536;    // problems (sampled over the range) run through the detector when nothing is cached yet
+constexpr uint64_t kLeanTile = 1ull << 28;      // problems per lean-kernel launch (straggler list: 4 B each)
+constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps without a cached cycle state), first guess
+constexpr uint32_t kFastStepsMax = 3072;
+constexpr uint64_t kProbeTile = 1ull << 22;     // lean tiles while the FAST length is being calibrated
+constexpr uint64_t kGeneralTile = 1ull << 32;   // problems per launch of the general kernel (32-bit offsets)
+constexpr uint64_t kUnresCap = 1ull << 18;      // cascade: unresolved classes a level may list
+constexpr uint64_t kNearBytes = 1ull << 30;     // cascade: list of the classes a level hands to the level below (segments + packed copy)
+
+using MergedTable = std::unordered_map<Key8, WideRec, Key8Hash>;
+
+struct AttractRun {
+    Counters ctr{};
+    float ms = 0.f;
+};
+
+// What a call adds up (wide: a call may cover 2^128 problems).
+struct Totals {
+    MergedTable merged;
+    u128 n_none = 0, steps_ref = 0;
+    uint64_t steps_exec = 0;
+    double kernel_ms = 0.0, dominant_ms = 0.0;
+    uint64_t dominant_exec = 0;
+    uint32_t launches = 0, dominant_launches = 0, limit_hits = 0, syncs = 0;
+};
+
+enum PassKind { kPassGeneral = 0, kPassLean = 1, kPassPool = 2 };
+
+WideRec& slot_for(MergedTable& merged, const uint32_t* key32, uint32_t nw, uint64_t length) {
+    const Key8 key = key8(key32);
+    auto it = merged.find(key);
+    if (it == merged.end()) {
+        WideRec a;
+        for (uint32_t w = 0; w < nw; ++w) a.key[w >> 1] |= (uint64_t)key32[w] << (32 * (w & 1));
+        a.length = length;
+        it = merged.emplace(key, a).first;
+    }
+    return it->second;
+}
+
+// merge by key (attract.py:405-455 write_aggregated_attractors_to_db, exact integers)
+void merge_records(MergedTable& merged, const LogRec* recs, size_t n, uint32_t nw) {
+    for (size_t i = 0; i < n; ++i) {
+        const LogRec& r = recs[i];
+        WideRec& a = slot_for(merged, r.key, nw, r.length);
+        a.count += r.count;
+        a.sum_l.add_at(r.sum_l, 0);
+        a.sum_l2.add_shifted(r.sum_l2_lo, r.sum_l2_hi, 0);
+    }
+}
+
+void fold_table(MergedTable& into, const MergedTable& from) {
+    for (const auto& kv : from) {
+        auto it = into.find(kv.first);
+        if (it == into.end()) { into.emplace(kv.first, kv.second); continue; }
+        WideRec& a = it->second;
+        a.count += kv.second.count;
+        a.sum_l.add(kv.second.sum_l);
+        a.sum_l2.add(kv.second.sum_l2);
+    }
+}
+
+// The sums a cube pass left in its Counters block (units of 2^shift problems + the absolute corrections of the
+// members that are cycle states themselves, bsx_device.h) -> merged, exact.
+void merge_cube_counters(MergedTable& merged, const Counters& c, uint32_t shift, uint32_t nw) {
+    for (uint32_t a = 0; a < 64; ++a) {
+        if (!c.acc_cnt[a] && !c.fix_cnt[a]) continue;
+        WideRec& r = slot_for(merged, c.acc_key[a], nw, c.acc_len[a]);
+        r.count += ((u128)c.acc_cnt[a] << shift) + (u128)(__int128)(int64_t)c.fix_cnt[a];
+        r.sum_l.add_shifted(c.acc_sl[a], 0, shift);
+        r.sum_l.add_signed((int64_t)c.fix_sl[a]);
+        r.sum_l2.add_shifted(c.acc_sl2_lo[a], c.acc_sl2_hi[a], shift);
+        r.sum_l2.add_signed((int64_t)c.fix_sl2[a]);
+    }
+}
+
+// LDS mirror size for the lean / pool kernels: they fill the mirror once from the journal, so it only has
+// to hold what the journal holds (4 slots per state keeps probe chains short); a smaller mirror leaves
+// the LDS to more workgroups.  The general kernel inserts while it runs and keeps the full size.
+int mirror_slots_for(bsx_handle h, uint32_t* slots_out) {
+    // At least 2 slots per entry (a cube pass adds one representative entry per state), 4 where that still lets
+    // two workgroups share a CU's LDS: at n = 64 a pool workgroup is 75.7 KiB + mirror, so a 256-slot mirror
+    // already halves the occupancy (measured: 3 instead of 6 waves per SIMD, profiles/r02_pmc notes).
+    const uint64_t entries = (h->cube_mirror ? 2 : 1) * h->journal_states;
+    uint32_t slots = 64;
+    while (slots < 2 * entries && slots < h->cache_lds_slots) slots *= 2;
+    const size_t fixed = h->shmem + 32 + pool_extra_bytes(h->net.nw);
+    while (slots < 4 * entries && slots < h->cache_lds_slots && fixed + (size_t)2 * slots * h->cache_stride <= 80 * 1024) slots *= 2;
+    h->mirror_slots = *slots_out = std::min(slots, h->cache_lds_slots);
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] mirror: %llu cycle states cached, %u slots\n", (unsigned long long)h->journal_states, *slots_out);
+    return BSX_OK;
+}
+
+int lean_mirror_slots(bsx_handle h, uint32_t* slots_out, Totals* tot = nullptr) {
+    uint32_t ignored = 0;
+    if (!slots_out) slots_out = &ignored;
+    if (!h->journal_stale) return mirror_slots_for(h, slots_out);
+    unsigned int known = 0;
+    HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+    if (tot) ++tot->syncs;
+    known = std::min<unsigned int>(known, kCycleJournalCap);
+    h->h_journal.resize(known);
+    if (known) HIPCHK(h, hipMemcpy(h->h_journal.data(), h->d_cc_journal.p, known * sizeof(CycleRecord), hipMemcpyDeviceToHost));
+    uint64_t states = 0;
+    uint32_t taken = 0;
+    for (const CycleRecord& r : h->h_journal) {
+        if (taken >= (uint32_t)kTagAcc + kLdsAcc) break;
+        if (!r.ready || r.length == 0 || r.length > kCycleCacheMaxLen) continue;
+        states += r.length;
+        ++taken;
+    }
+    h->journal_states = states;
+    h->journal_stale = false;
+    return mirror_slots_for(h, slots_out);
+}
+
+// The pool kernel's cache mirror as an image in HBM: rebuilt (one workgroup) only when the journal or the mirror
+// size has changed; every workgroup of the passes that follow copies it instead of regenerating the cycles.
+int ensure_mirror_image(bsx_handle h, AttractParams& P, size_t shmem) {
+    if (std::getenv("BSX_MIRROR_IMAGE") && std::getenv("BSX_MIRROR_IMAGE")[0] == '0') { P.mirror_image = nullptr; P.mirror_out = nullptr; return BSX_OK; }
+    const size_t words = 4 + (size_t)P.cc.lds_slots * (h->cache_stride / 4);
+    if (h->image_n != h->h_journal.size() || h->image_slots != P.cc.lds_slots || h->d_mirror.n < words) {
+        HIPCHK(h, h->d_mirror.reserve(words));
+        AttractParams B = P;
+        B.count = 0;
+        B.level_in = nullptr;
+        B.mirror_image = nullptr;
+        B.mirror_out = h->d_mirror.p;
+        HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, dim3(1), shmem, h->stream, B));
+        h->image_n = h->h_journal.size();
+        h->image_slots = P.cc.lds_slots;
+    }
+    P.mirror_image = h->d_mirror.p;
+    P.mirror_out = nullptr;
+    return BSX_OK;
+}
+
+double g_prof[6];       // BSX_PROFILE: host time per section of a pass, ms
+
+// One launch of the general / lean / pool kernel over P.count work items + merge of its log into `merged` (null:
+// results discarded).  The host waits for it: these passes decide what runs next (stragglers, calibration).
+int launch_attract_pass(bsx_handle h, AttractParams& P, int kind, DevBuf<LogRec>& d_log, MergedTable* merged,
+                        AttractRun& run, Totals& tot) {
+    const double pt0 = now_ms();
+    const bool fast = kind != kPassGeneral;
+    if (!fast) h->journal_stale = true;         // the detector may publish attractors
+    size_t shmem = h->shmem_attract;
+    if (fast) {
+        uint32_t slots = h->cache_lds_slots;
+        if (int rc = lean_mirror_slots(h, &slots, &tot)) return rc;
+        P.cc.lds_slots = slots;
+        shmem = h->shmem + (size_t)slots * h->cache_stride + 32 + (kind == kPassPool ? pool_extra_bytes(h->net.nw) : lean_acc_bytes(h->net.nw));
+    }
+    const Launch L = plan_persistent(h, P.count, shmem);
+    P.chunk = L.chunk;
+    // plain tiles, whose cost per problem varies by region: every wave starts with one piece and takes the rest from the
+    // cursor (measured on config 3's plain tiles: fixed three-quarter shares 2.5 ms against 1.9 ms)
+    if (kind == kPassPool) P.chunk_first = P.chunk;
+    if (const char* c = std::getenv("BSX_CHUNK")) { P.chunk = (uint32_t)std::max(64, std::atoi(c)); P.chunk_first = P.chunk; }     // tuning knob
+    const uint64_t waves = (uint64_t)L.grid.x * kWavesPerBlock;
+    const uint64_t log_cap = waves * kTableSlots + (1u << 16);
+    if (d_log.n < log_cap) HIPCHK(h, d_log.alloc(log_cap));
+    P.log = d_log.p;
+    P.log_cap = log_cap;
+    P.ctr = h->d_ctr;
+    P.level_in = nullptr;
+    // results that are kept may spill from the log into the HBM attractor table (general kernel only: the
+    // lean / pool kernels write at most one record per workgroup and cached attractor)
+    P.table = (merged && !fast && h->table_slots) ? h->d_table.p : nullptr;
+    P.table_mask = h->table_slots ? h->table_slots - 1 : 0;
+    if (kind == kPassPool) if (int rc = ensure_mirror_image(h, P, shmem)) return rc;
+    const double pt1 = now_ms();
+    HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (kind == kPassPool) HIPCHK(h, launch_attract_pool((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+    else if (kind == kPassLean) HIPCHK(h, launch_attract_fast((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+    else HIPCHK(h, launch_attract((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    const double pt2 = now_ms();
+    HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ++tot.syncs;
+    run.ctr = *h->h_ctr;
+    const double pt3 = now_ms();
+    HIPCHK(h, hipEventElapsedTime(&run.ms, h->ev0, h->ev1));
+    g_prof[0] += pt1 - pt0; g_prof[1] += pt2 - pt1; g_prof[2] += pt3 - pt2; g_prof[3] += run.ms;
+    if (std::getenv("BSX_DEBUG"))
+        std::fprintf(stderr, "[bsx] %s pass: %llu problems, %llu lane-steps, %llu stragglers, %.3f ms (BSX_DIAG build: %llu wave iterations, %llu service rounds)\n",
+                     kind == kPassPool ? "pool" : fast ? "lean" : "general", (unsigned long long)P.count, (unsigned long long)run.ctr.steps_exec,
+                     (unsigned long long)run.ctr.n_stragglers, run.ms, (unsigned long long)run.ctr.wave_iters,
+                     (unsigned long long)run.ctr.service_rounds);
+    if (std::getenv("BSX_DEBUG") && run.ctr.wave_iters)
+        std::fprintf(stderr, "[bsx]   diag: kept after fresh stages %llu, lanes into pool stages %llu, kept after pool stages %llu, merged away %llu\n",
+                     (unsigned long long)run.ctr.diag[0], (unsigned long long)run.ctr.diag[1], (unsigned long long)run.ctr.diag[2], (unsigned long long)run.ctr.diag[3]);
+    if (std::getenv("BSX_DEBUG") && run.ctr.phase_max[0])
+        std::fprintf(stderr, "[bsx]   diag: %u workgroups; prologue / loop / epilogue, us: mean %.1f / %.1f / %.1f, slowest %.1f / %.1f / %.1f\n", L.grid.x,
+                     run.ctr.phase_sum[0] / 100.0 / L.grid.x, run.ctr.phase_sum[1] / 100.0 / L.grid.x, run.ctr.phase_sum[2] / 100.0 / L.grid.x,
+                     run.ctr.phase_max[0] / 100.0, run.ctr.phase_max[1] / 100.0, run.ctr.phase_max[2] / 100.0);
+    if (!merged) return BSX_OK;                 // results discarded (discovery): a full log does not matter
+    if (run.ctr.table_inserts) h->table_dirty = true;
+    if (run.ctr.log_overflow) return fail(h, BSX_ERR_TABLE_FULL, "device attractor log overflowed");
+    if (run.ctr.table_overflow) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity (device table full)");
+    const uint64_t n_log = std::min<uint64_t>(run.ctr.log_cursor, log_cap);
+    std::vector<LogRec> log(n_log);
+    if (n_log) { HIPCHK(h, hipMemcpy(log.data(), d_log.p, n_log * sizeof(LogRec), hipMemcpyDeviceToHost)); ++tot.syncs; }
+    merge_records(*merged, log.data(), log.size(), h->net.nw);
+    return BSX_OK;
+}
+
+}  // namespace
+
+namespace bsx {
+
+// ---- cube collapse: which of the `a` lowest initial-state digits can the FIRST update of the
+// block starting at digit value d_lo depend on?  A node's rule, restricted to the block's fixed bits, depends
+// on a free predecessor iff flipping it changes the output for some assignment of the rule's other free
+// inputs; a digit is relevant iff its node is such a predecessor of some node (fixed nodes have constant
+// rules, model.py:45-47).  f(s) is then a function of the relevant digits alone -- exactly, not heuristically.
+void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const uint32_t* fixmask) {
+    if (!fixmask) fixmask = h->sp.fixmask;      // (target passes: the fixed nodes of the block's fixed-node variant)
+    const uint32_t n = h->n_nodes, nw = h->net.nw;
+    c.d_lo = d_lo; c.a = a; c.rel.clear(); c.ok = false;
+    uint32_t base[kMaxW32];     // origin bits + the block's fixed digits
+    for (int w = 0; w < kMaxW32; ++w) { base[w] = h->sp.origin[w]; c.umask[w] = 0; c.free_mask[w] = 0; }
+    std::vector<char> is_free(n, 0), relevant(n, 0);
+    for (uint32_t j = 0; j < h->sp.n_any; ++j) {
+        const uint32_t node = h->h_any[j];
+        if (j < a) { is_free[node] = 1; c.free_mask[node >> 5] |= 1u << (node & 31); }
+        else if ((d_lo >> j) & 1ull) base[node >> 5] |= 1u << (node & 31);
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((fixmask[i >> 5] >> (i & 31)) & 1u) continue;
+        const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
+        const uint32_t* preds = h->h_pred_idx.data() + h->h_pred_offsets[i];
+        if (k > (uint32_t)kMaxMuxK) {                    // wide rule: every free input counts (conservative)
+            for (uint32_t j = 0; j < k; ++j) if (is_free[preds[j]]) relevant[preds[j]] = 1;
+            continue;
+        }
+        const uint64_t tt = h->h_tt0[i];
+        uint32_t free_slots = 0, fixed_idx = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+            if (is_free[preds[j]]) free_slots |= 1u << j;
+            else if ((base[preds[j] >> 5] >> (preds[j] & 31)) & 1u) fixed_idx |= 1u << j;
+        }
+        for (uint32_t j = 0; j < k; ++j) {
+            if (!((free_slots >> j) & 1u) || relevant[preds[j]]) continue;
+            const uint32_t others = free_slots & ~(1u << j);
+            uint32_t x = 0;
+            do {                                        // all assignments of the other free inputs
+                const uint32_t idx = fixed_idx | x;
+                if (((tt >> idx) ^ (tt >> (idx | (1u << j)))) & 1ull) { relevant[preds[j]] = 1; break; }
+                x = (x - others) & others;
+            } while (x);
+        }
+    }
+    for (uint32_t j = 0; j < a; ++j) {
+        const uint32_t node = h->h_any[j];
+        if (relevant[node]) c.rel.push_back(j);
+        else c.umask[node >> 5] |= 1u << (node & 31);
+    }
+    for (uint32_t w = 0; w < (uint32_t)kMaxW32; ++w) c.base[w] = w < nw ? base[w] : 0u;
+    c.ok = c.rel.size() <= kMaxDepositRuns;
+}
+
+// Enumeration space of the cube: class-index bit q -> the node of c.rel[q] (one deposit run per relevant
+// digit, in the order c.rel lists them), everything else fixed.
+void plan_cube(const bsx_engine* h, Cube& c) {
+    DevSpace sp = h->sp;
+    for (uint32_t w = 0; w < (uint32_t)kMaxW32; ++w) sp.origin[w] = c.base[w];
+    sp.n_any = (uint32_t)c.rel.size();
+    sp.identity_any = 0;
+    for (int w = 0; w < 4; ++w) sp.first_digits[w] = 0;
+    sp.first_variant = 0;
+    sp.n_runs = (uint32_t)c.rel.size();
+    for (uint32_t q = 0; q < c.rel.size(); ++q) {
+        const uint32_t node = h->h_any[c.rel[q]];
+        sp.deposit[2 * q] = q | (node >> 5) << 8 | (node & 31u) << 16;
+        sp.deposit[2 * q + 1] = 1u;
+    }
+    c.sp = sp;
+}
+
+}  // namespace bsx
+
+namespace {
+
+// Deeper collapse: the digits of the block that F^d(x) still depends on, d = 1 .. max_depth, as masks over the
+// digit index (out[d - 1]; a <= 63).  Constant propagation over the block: a node's value after s updates is
+// 0, 1 or "varies" with the set of free digits it may depend on; a rule is restricted to the inputs that are
+// constant over the block and counts a varying input only if the restricted truth table is sensitive to it.
+// An over-approximation (never misses a dependence), and out[0] is build_cube's set.  out[d] is a subset of
+// out[d - 1]: the members of a depth-d class share F^d(x) and everything after it.
+void cube_levels(const bsx_engine* h, const Cube& c, uint32_t max_depth, std::vector<uint64_t>& out) {
+    const uint32_t n = h->n_nodes;
+    const uint32_t* fixmask = h->sp.fixmask;
+    std::vector<uint8_t> val(n), nval(n);       // 0 / 1 / 2 = varies
+    std::vector<uint64_t> dep(n, 0), ndep(n, 0);
+    for (uint32_t i = 0; i < n; ++i) val[i] = (c.base[i >> 5] >> (i & 31)) & 1u;
+    for (uint32_t j = 0; j < c.a; ++j) { const uint32_t node = h->h_any[j]; val[node] = 2; dep[node] = 1ull << j; }
+    out.clear();
+    for (uint32_t d = 1; d <= max_depth; ++d) {
+        uint64_t all = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            ndep[i] = 0;
+            if ((fixmask[i >> 5] >> (i & 31)) & 1u) { nval[i] = (h->sp.fixval[i >> 5] >> (i & 31)) & 1u; continue; }
+            const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
+            const uint32_t* preds = h->h_pred_idx.data() + h->h_pred_offsets[i];
+            if (k > (uint32_t)kMaxMuxK) {                // wide rule: varies with whatever its inputs vary with (conservative)
+                nval[i] = 2;
+                for (uint32_t j = 0; j < k; ++j) ndep[i] |= dep[preds[j]];
+                continue;
+            }
+            const uint64_t tt = h->h_tt0[i];
+            uint32_t var_slots = 0, fixed_idx = 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                if (val[preds[j]] == 2) var_slots |= 1u << j;
+                else if (val[preds[j]]) fixed_idx |= 1u << j;
+            }
+            uint32_t seen = 0, sens = 0, x = 0;
+            do {                                        // all assignments of the varying inputs
+                const uint32_t idx = fixed_idx | x;
+                seen |= 1u << ((tt >> idx) & 1ull);
+                for (uint32_t j = 0; j < k; ++j)
+                    if (((var_slots >> j) & 1u) && (((tt >> idx) ^ (tt >> (idx ^ (1u << j)))) & 1ull)) sens |= 1u << j;
+                x = (x - var_slots) & var_slots;
+            } while (x);
+            if (seen != 3u) { nval[i] = seen >> 1; continue; }
+            nval[i] = 2;
+            for (uint32_t j = 0; j < k; ++j) if ((sens >> j) & 1u) ndep[i] |= dep[preds[j]];
+        }
+        // the origin's perturbation schedule overrides the rules at time d (model.py:68-71): constants for every member
+        for (size_t e = 0; e + 2 < h->h_sched.size(); e += 3)
+            if (h->h_sched[e] == d) { nval[h->h_sched[e + 1]] = (uint8_t)h->h_sched[e + 2]; ndep[h->h_sched[e + 1]] = 0; }
+        all = 0;
+        for (uint32_t i = 0; i < n; ++i) all |= ndep[i];
+        out.push_back(all);
+        val.swap(nval);
+        dep.swap(ndep);
+    }
+}
+
+// Relevant digits whose influence dies out first become the lowest class-index bits (k_digit_lifetimes):
+// the classes that merge after a step or two then sit in the same batch.  A heuristic for speed only.
+int order_cube_digits(bsx_handle h, Cube& c) {
+    const uint32_t r = (uint32_t)c.rel.size();
+    if (r < 2 || r > 64 || (std::getenv("BSX_CUBE_ORDER") && std::getenv("BSX_CUBE_ORDER")[0] == '0')) return BSX_OK;
+    uint64_t need = 0;
+    for (uint32_t q = 0; q < r; ++q) need |= 1ull << c.rel[q];
+    // (measured once per digit and problem space: the launch + copy + wait would otherwise sit inside every call)
+    if (need & ~h->life_valid) {
+        LifetimeParams L{};
+        L.net = h->net;
+        for (int w = 0; w < kMaxW32; ++w) { L.fixmask[w] = h->sp.fixmask[w]; L.fixval[w] = h->sp.fixval[w]; L.base[w] = c.base[w]; L.free_mask[w] = c.free_mask[w]; }
+        L.n_digits = r;
+        for (uint32_t q = 0; q < r; ++q) L.node[q] = h->h_any[c.rel[q]];
+        HIPCHK(h, h->d_life.reserve(64));
+        HIPCHK(h, hipMemsetAsync(h->d_life.p, 0, 64 * sizeof(uint32_t), h->stream));
+        L.out = h->d_life.p;
+        HIPCHK(h, launch_digit_lifetimes((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, h->shmem, h->stream, L));
+        uint32_t measured[64];
+        HIPCHK(h, hipMemcpyAsync(measured, h->d_life.p, sizeof(measured), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (uint32_t q = 0; q < r; ++q) h->life_cache[c.rel[q]] = measured[q];
+        h->life_valid |= need;
+    }
+    uint32_t life[64];
+    for (uint32_t q = 0; q < r; ++q) life[q] = h->life_cache[c.rel[q]];
+    std::vector<uint32_t> idx(r);
+    for (uint32_t q = 0; q < r; ++q) idx[q] = q;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return life[x] < life[y]; });
+    std::vector<uint32_t> rel(r);
+    for (uint32_t q = 0; q < r; ++q) rel[q] = c.rel[idx[q]];
+    c.rel = rel;
+    return BSX_OK;
+}
+
+// Entries of the HBM attractor table -> `merged`; the table is left empty for the next call.
+int drain_attractor_table(bsx_handle h, MergedTable& merged) {
+    if (!h->table_dirty) return BSX_OK;
+    h->table_dirty = false;
+    DevBuf<unsigned long long> d_cursor;
+    DevBuf<LogRec> d_out;
+    HIPCHK(h, d_cursor.alloc(1));
+    HIPCHK(h, hipMemsetAsync(d_cursor.p, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, d_out.alloc(h->table_slots));
+    HIPCHK(h, launch_table_drain(h->d_table.p, h->table_slots, d_out.p, h->table_slots, d_cursor.p, h->stream));
+    unsigned long long n = 0;
+    HIPCHK(h, hipMemcpyAsync(&n, d_cursor.p, sizeof(n), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<LogRec> recs(n);
+    if (n) HIPCHK(h, hipMemcpy(recs.data(), d_out.p, n * sizeof(LogRec), hipMemcpyDeviceToHost));
+    merged.reserve(merged.size() + n);
+    merge_records(merged, recs.data(), recs.size(), h->net.nw);
+    return BSX_OK;
+}
+
+int ensure_attractor_table(bsx_handle h, uint32_t cap) {
+    if (h->table_dirty) { MergedTable stale; if (int rc = drain_attractor_table(h, stale)) return rc; }     // a failed call left entries behind
+    // HBM attractor table behind the log: two slots per entry of the caller's table (kept zeroed between calls)
+    uint64_t want = 1ull << 16;
+    while (want < 2 * (uint64_t)cap) want *= 2;
+    if (h->table_slots < want) {
+        HIPCHK(h, h->d_table.alloc(want));
+        HIPCHK(h, hipMemset(h->d_table.p, 0, want * sizeof(LogRec)));
+        h->table_slots = want;
+        h->table_dirty = false;
+    }
+    return BSX_OK;
+}
+
+// first + delta for spaces whose initial-state digits fit one word (the fast path's precondition)
+void advance_first(DevSpace& sp, const bsx_index& first, uint64_t delta) {
+    for (int w = 0; w < 4; ++w) sp.first_digits[w] = first.init_digits[w];
+    sp.first_digits[0] += delta;
+    sp.first_variant = first.variant;
+}
+
+// The counter blocks of a finished chain -> h->h_ctr, and the one wait of the chain.  k_publish, the chain's last
+// kernel, stores the blocks into the pinned host buffer and then the call's sequence number into h->h_flag; the host
+// spins on that word (asking the stream now and then whether it has failed) instead of sleeping in
+// hipStreamSynchronize behind a DMA copy, whose wake-up cost tens of microseconds per call.  BSX_SPIN_WAIT=0: the
+// plain copy + wait.
+int fetch_counters(bsx_handle h, uint32_t n_blocks) {
+    static const bool spin = !(std::getenv("BSX_SPIN_WAIT") && std::getenv("BSX_SPIN_WAIT")[0] == '0');
+    if (!spin) {
+        HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters) * n_blocks, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return BSX_OK;
+    }
+    const uint32_t seq = ++h->flag_seq ? h->flag_seq : ++h->flag_seq;       // never 0
+    HIPCHK(h, launch_publish(reinterpret_cast<const uint32_t*>(h->d_ctr), reinterpret_cast<uint32_t*>(h->h_ctr),
+                             (uint32_t)(sizeof(Counters) / 4 * n_blocks), const_cast<uint32_t*>(h->h_flag), seq, h->stream));
+    uint32_t polls = 0;
+    while (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != seq) {
+        __builtin_ia32_pause();
+        if ((++polls & 0xFFFFu) == 0) {                     // every few hundred microseconds: is the stream still alive?
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {                          // drained; the flag store is visible by now, or never will be
+                if (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+                return fail(h, BSX_ERR_HIP, "the cascade finished without publishing its counters");
+            }
+            if (q != hipErrorNotReady) { h->error = std::string("hipStreamQuery: ") + hipGetErrorString(q); return BSX_ERR_HIP; }
+        }
+    }
+    return BSX_OK;
+}
+
+// ---- one cube: the whole cascade as ONE chain of launches -----------------------------------------------------------
+// Level d of a block enumerates the assignments of the digits F^d still depends on (top level) or, below it, the digits
+// level d adds on top of every class the level above has listed as "near a cycle" (DESIGN.md "Deeper collapse").  How many
+// classes a level lists is only known on the device, so the chain is enqueued blind: k_compact_near packs the list and
+// writes its length into a LevelDesc, the next level's launch (full persistent grid) reads it there and sizes its own
+// work split.  Every level counts into its own Counters block; the host waits once, reads all blocks, and only then
+// looks at what happened: a segment overflow (-> the block is redone from a shallower top), unresolved classes
+// (attractors nobody has cached yet -> the detector runs from the listed states; if one of them sat on a cycle the
+// block is repeated with the richer cache).  Passes are accepted or discarded whole.
+struct CascadeEnv {
+    const AttractParams& P;         // the call's template (network, caps, cache)
+    uint64_t max_t, max_len;
+    Totals& tot;
+    DevBuf<LogRec>& d_log;
+};
+
+int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapsed) {
+    collapsed = false;
+    const AttractParams& P = env.P;
+    Totals& tot = env.tot;
+    const uint64_t max_t = env.max_t, max_len = env.max_len;
+    const uint32_t nw = h->net.nw, rec_words = nw + 3;
+    const uint64_t tp = h->sp.tp_origin;            // the search starts at s(T_p); class times count from there
+    const uint64_t cap_rel = max_t == BSX_T_INF ? BSX_T_INF : max_t - tp;
+    const uint32_t cap_rel32 = (cap_rel == BSX_T_INF || cap_rel >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)cap_rel;
+    const uint32_t fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
+
+    // ---- levels: rel_mask[d - 1] = digits F^d depends on.  BSX_CUBE_DEPTH caps the top level (1 = first update only) ...
+    uint32_t max_depth = 8;
+    if (const char* e = std::getenv("BSX_CUBE_DEPTH")) max_depth = (uint32_t)std::max(1, std::min((int)kMaxCubeLevels, std::atoi(e)));
+    if (h->cube_depth_cap) max_depth = std::min(max_depth, h->cube_depth_cap);
+    // with a warm-up the search starts at s(T_p): classes that share F^d, d <= T_p, share every state that counts,
+    // so no class has to be handed down -- one pass at the best such depth
+    if (tp) max_depth = (uint32_t)std::min<uint64_t>(max_depth, tp);
+    max_depth = std::max(1u, std::min(max_depth, fast_steps > 1 ? fast_steps - 1 : 1u));
+    std::vector<uint64_t> rel_mask;
+    cube_levels(h, c1, max_depth, rel_mask);
+    // ... and otherwise the top is the depth that minimises an estimate: 12 us per level of the chain (prologue of the
+    // launch + the packing kernel behind it; nothing waits for the host between levels) and 2^|R_d| classes x (d + 0.3)
+    // updates at 2.4e11 class updates per second, so that small blocks are not pushed through levels that save less
+    // than they cost.  (An explicit BSX_CUBE_DEPTH keeps the plain rule "fewest digits": tests force levels onto small spaces.)
+    const bool forced_depth = std::getenv("BSX_CUBE_DEPTH") != nullptr;
+    uint32_t top = 1;
+    double best = 0;
+    for (uint32_t d = 1; d <= max_depth; ++d) {
+        const int r_d = __builtin_popcountll(rel_mask[d - 1]);
+        const double est = forced_depth ? (double)r_d : 12.0 * d + std::ldexp(1.0, r_d) * (d + 0.3) / 2.4e5;
+        if (d == 1 || est < best) { best = est; top = d; }
+    }
+    auto level_cube = [&](uint64_t digits, bool ordered, Cube& lc) -> int {
+        lc = c1;
+        lc.rel.clear();
+        for (uint32_t j = 0; j < c1.a; ++j) if ((digits >> j) & 1ull) lc.rel.push_back(j);
+        if (ordered) if (int rc = order_cube_digits(h, lc)) return rc;
+        plan_cube(h, lc);
+        return BSX_OK;
+    };
+
+    for (int attempt = 0; attempt < 32; ++attempt) {
+        // every cached attractor must be in the mirror, or a class could sit on a cycle nobody recognises
+        uint32_t slots = 0;
+        h->cube_mirror = true;
+        const int rc_m = lean_mirror_slots(h, &slots, &tot);
+        h->cube_mirror = false;
+        if (rc_m) return rc_m;
+        uint64_t states = 0;
+        for (const CycleRecord& jr : h->h_journal) states += jr.length;
+        if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 4 * states > h->cache_lds_slots) return BSX_OK;
+        if (top < 1) top = 1;
+        // a pass may not have more classes than its 49-bit member counts (in units of one fresh class) can add up
+        if (__builtin_popcountll(rel_mask[top - 1]) > 47) return BSX_OK;
+
+        // ---- plan the chain: level index i = 0 (top, depth `top`) .. top - 1 (depth 1)
+        const uint32_t n_levels = top;
+        struct Level { uint32_t depth, k_bits, r_here, unit_shift; uint64_t classes; Cube cube; };
+        std::vector<Level> lv(n_levels);
+        for (uint32_t i = 0; i < n_levels; ++i) {
+            const uint32_t d = top - i;
+            const uint64_t here = rel_mask[d - 1];
+            lv[i].depth = d;
+            lv[i].r_here = (uint32_t)__builtin_popcountll(here);
+            if (int rc = level_cube(i == 0 ? here : here & ~rel_mask[d], i == 0, lv[i].cube)) return rc;
+            lv[i].k_bits = (uint32_t)lv[i].cube.rel.size();
+            lv[i].unit_shift = c1.a - lv[i].r_here;         // members of one fresh class = the unit of this level's counts
+            lv[i].classes = 0;
+        }
+        const size_t shmem = h->shmem + (size_t)slots * h->cache_stride + 32 + pool_extra_bytes(h->net.nw);
+        const Launch full = plan_persistent(h, ~0ull >> 8, shmem);         // the persistent grid (lower levels: size unknown here)
+        const uint64_t seg_cap = std::getenv("BSX_CUBE_NEAR_CAP") ? (uint64_t)std::max(1, std::atoi(std::getenv("BSX_CUBE_NEAR_CAP")))     // (tests: force the shallower restart)
+                                                                    : std::max<uint64_t>(1, kNearBytes / (4 * nw) / full.grid.x);
+        if (n_levels > 1) {
+            HIPCHK(h, h->d_near_seg.reserve((size_t)full.grid.x * seg_cap * nw));
+            HIPCHK(h, h->d_near_counts.reserve(full.grid.x));
+            HIPCHK(h, h->d_near_list.reserve((size_t)full.grid.x * seg_cap * nw));
+        }
+        HIPCHK(h, h->d_unres.reserve((size_t)n_levels * kUnresCap * rec_words));
+
+        AttractParams Q0 = P;
+        Q0.cc.lds_slots = slots;
+        Q0.merge = 3;
+        Q0.fast_steps = fast_steps;
+        Q0.per_problem = nullptr;
+        Q0.offsets = nullptr;
+        Q0.states = nullptr;
+        Q0.log = nullptr; Q0.log_cap = 0; Q0.table = nullptr; Q0.table_mask = 0;
+        for (int w = 0; w < kMaxW32; ++w) { Q0.cube_umask[w] = c1.umask[w]; Q0.cube_free[w] = c1.free_mask[w]; }
+        if (int rc = ensure_mirror_image(h, Q0, shmem)) return rc;
+
+        const double pt0 = now_ms();
+        // (descriptors and the levels' counter blocks are one stretch of memory: one fill)
+        HIPCHK(h, hipMemsetAsync(h->d_level, 0, kLevelDescBytes + sizeof(Counters) * n_levels, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        for (uint32_t i = 0; i < n_levels; ++i) {
+            const Level& l = lv[i];
+            AttractParams Q = Q0;
+            Q.sp = l.cube.sp;
+            Q.ctr = h->d_ctr + i;
+            Q.cube_shift = 0;                               // counts in units of one fresh class (2^unit_shift problems)
+            Q.cube_depth = l.depth;
+            Q.entry_shift = l.k_bits;
+            Q.stragglers = h->d_unres.p + (size_t)i * kUnresCap * rec_words;
+            Q.stragglers_cap = kUnresCap * rec_words;
+            Q.near = l.depth > 1 ? h->d_near_seg.p : nullptr;
+            Q.near_counts = l.depth > 1 ? h->d_near_counts.p : nullptr;
+            Q.near_cap = l.depth > 1 ? seg_cap : 0;
+            dim3 grid = full.grid;
+            if (i == 0) {
+                Q.count = 1ull << l.k_bits;
+                Q.entries = nullptr;
+                Q.level_in = nullptr;
+                const Launch L = plan_persistent(h, Q.count, shmem);
+                // the top level lists into per-workgroup segments sized for the full grid: keep that grid when it lists
+                grid = L.grid;
+                const uint64_t n_waves = (uint64_t)grid.x * (kPoolBlockThreads / 64);
+                // passes under 2^28 classes: even fixed shares, no traffic on the cursor's one address (their classes
+                // cost about the same everywhere); larger ones: one piece each, the rest from the cursor
+                if (Q.count < (1ull << 28)) { Q.chunk_first = ((Q.count + n_waves - 1) / n_waves + 63) / 64 * 64; Q.chunk = 0; }
+                else { Q.chunk_first = L.chunk; Q.chunk = L.chunk; }
+                if (const char* c = std::getenv("BSX_CHUNK")) { Q.chunk = (uint32_t)std::max(64, std::atoi(c)); Q.chunk_first = Q.chunk; }
+                HIPCHK(h, hipEventRecord(h->ev_top0, h->stream));
+            } else {
+                Q.count = 0;
+                Q.entries = h->d_near_list.p;               // (packed by the k_compact_near before this launch)
+                Q.level_in = h->d_level + i;
+                Q.chunk = 0; Q.chunk_first = 0;
+            }
+            HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem, h->stream, Q));
+            if (i == 0) HIPCHK(h, hipEventRecord(h->ev_top1, h->stream));
+            if (l.depth > 1)
+                HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, seg_cap, nw, h->d_near_list.p, h->d_level + i + 1, h->stream));
+        }
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        const double pt1 = now_ms();
+        if (int rc = fetch_counters(h, n_levels)) return rc;
+        ++tot.syncs;
+        const double pt2 = now_ms();
+        float ms = 0.f, ms_top = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) {      // (events precede k_publish: complete by now, but ask nicely)
+            HIPCHK(h, hipEventSynchronize(h->ev1));
+            HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        }
+        HIPCHK(h, hipEventElapsedTime(&ms_top, h->ev_top0, h->ev_top1));
+        g_prof[1] += pt1 - pt0; g_prof[2] += pt2 - pt1; g_prof[3] += ms;
+        tot.kernel_ms += ms;
+        tot.launches += 2 * n_levels - 1;
+        tot.dominant_ms += ms_top;
+        tot.dominant_exec += h->h_ctr[0].steps_exec;
+        ++tot.dominant_launches;
+
+        // ---- what happened, top down
+        MergedTable pass_table;
+        u128 pass_none = 0, pass_ref = 0;
+        bool repeat = false, lower = false, give_up = false;
+        uint64_t n_entries = 0;
+        for (uint32_t i = 0; i < n_levels && !repeat && !lower; ++i) {
+            const Level& l = lv[i];
+            const Counters& c = h->h_ctr[i];
+            const uint64_t classes = i == 0 ? 1ull << l.k_bits : n_entries << l.k_bits;
+            if (i > 0 && n_entries == 0) break;
+            tot.steps_exec += c.steps_exec;
+            if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] cube 2^%u at digit value %llu: depth %u%s, %u digits here (%u relevant), %llu classes, %llu near a cycle, %llu unresolved\n", c1.a, (unsigned long long)c1.d_lo, l.depth, i == 0 ? " (top)" : "", l.k_bits, l.r_here, (unsigned long long)classes, (unsigned long long)c.near_classes, (unsigned long long)c.straggler_classes);
+            if (c.straggler_overflow) { give_up = true; break; }    // too many unresolved classes: not a space for cubes
+            if (c.near_overflow) { top = l.depth - 1; h->cube_depth_cap = top; lower = true; break; }     // start over, shallower
+            // a level whose classes mostly sit next to a cycle only adds work: later blocks stop above it
+            if (l.depth > 1 && 2 * c.near_classes > classes) h->cube_depth_cap = l.depth - 1;
+            n_entries = c.near_classes;
+            const uint32_t us = l.unit_shift;
+            merge_cube_counters(pass_table, c, us, nw);
+            pass_none += ((u128)c.n_none << us) + (u128)(__int128)(int64_t)c.fix_none;
+            pass_ref += ((u128)c.steps_ref << us) + (u128)(__int128)(int64_t)c.fix_ref +
+                        (max_t == BSX_T_INF ? (u128)0 : (u128)((__int128)(int64_t)c.fix_capfail * (__int128)max_t));
+            const uint64_t n_unres = c.straggler_classes;
+            if (!n_unres) continue;
+            // the detector runs from each listed state: a class that was not on a cycle yet gets its exact
+            // result (all members share the rest of the trajectory); one that sits on a cycle needs that
+            // attractor in the cache -- the detector has just published it -- and the pass is repeated
+            if (n_unres > kUnresCap) { give_up = true; break; }
+            std::vector<uint32_t> recs(n_unres * rec_words);
+            HIPCHK(h, hipMemcpy(recs.data(), h->d_unres.p + (size_t)i * kUnresCap * rec_words, recs.size() * 4, hipMemcpyDeviceToHost));
+            ++tot.syncs;
+            std::vector<uint32_t> st(n_unres * nw);
+            for (uint64_t q = 0; q < n_unres; ++q) std::copy(recs.begin() + q * rec_words, recs.begin() + q * rec_words + nw, st.begin() + q * nw);
+            DevBuf<uint32_t> d_states;
+            DevBuf<ProblemRec32> d_res;
+            HIPCHK(h, d_states.upload(st));
+            HIPCHK(h, d_res.alloc(n_unres));
+            AttractParams S = P;
+            S.sp = l.cube.sp;
+            S.sp.tp_origin = 0;                     // the listed states are past the warm-up
+            S.count = n_unres;
+            S.states = d_states.p;
+            S.per_problem = d_res.p;
+            S.max_len = BSX_T_INF;
+            S.merge = 0;
+            AttractRun rs;
+            if (int rc2 = launch_attract_pass(h, S, kPassGeneral, env.d_log, nullptr, rs, tot)) return rc2;
+            tot.kernel_ms += rs.ms; ++tot.launches; tot.steps_exec += rs.ctr.steps_exec; tot.limit_hits += rs.ctr.step_limit_hits;
+            std::vector<ProblemRec32> res(n_unres);
+            HIPCHK(h, hipMemcpy(res.data(), d_res.p, n_unres * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
+            ++tot.syncs;
+            for (uint64_t q = 0; q < n_unres && !repeat; ++q) {
+                const uint32_t* rec = recs.data() + q * rec_words;
+                const uint64_t t_class = rec[nw];
+                const u128 m = (u128)(((uint64_t)rec[nw + 2] << 32) | rec[nw + 1]) << us;
+                const ProblemRec32& pr = res[q];
+                if (!pr.found) { pass_none += m; pass_ref += m * max_t; continue; }        // (finite cap, or the step limit was hit)
+                if (pr.trajectory_l == 0) { repeat = true; break; }                          // on a cycle: members' mu unknown
+                const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length, traj = tp + mu;
+                const bool found = cap_rel == BSX_T_INF || mu + lam <= cap_rel;
+                pass_ref += found ? m * (traj + lam) : m * max_t;
+                if (!found || lam > max_len) { pass_none += m; continue; }
+                WideRec& e = slot_for(pass_table, pr.key, nw, lam);
+                e.count += m;
+                e.sum_l.add_mul(m, traj);
+                e.sum_l2.add_mul(m, traj * traj);               // traj < 2^31 here (32-bit device counters)
+            }
+        }
+        if (give_up) return BSX_OK;
+        if (lower) continue;
+        if (repeat) {
+            unsigned int known = 0;
+            HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+            ++tot.syncs;
+            if (known <= h->h_journal.size()) return BSX_OK;        // the attractor cannot be cached: no cube for this block
+            continue;                                               // (the detector pass marked the journal stale)
+        }
+        fold_table(tot.merged, pass_table);
+        tot.n_none += pass_none;
+        tot.steps_ref += pass_ref;
+        collapsed = true;
+        return BSX_OK;
+    }
+    return BSX_OK;
+}
+
+// ---- one segment: [first, first + count) inside the space the handle currently describes ------------------------------
+// (for a plain space -- no variations, at most 64 'any' nodes -- the segment lies within its 2^n_any initial states,
+// count <= 2^64; with variations the index carries into the variant number)
+int attract_segment(bsx_handle h, const bsx_index& first, u128 count, uint64_t max_t, uint64_t max_len,
+                    bsx_problem_rec* per_problem, Totals& tot) {
+    DevBuf<LogRec>& d_log = h->d_log;
+    DevBuf<ProblemRec32> d_pp;
+    if (per_problem) HIPCHK(h, d_pp.alloc((size_t)count));
+
+    AttractParams P{};
+    P.net = h->net;
+    P.sp = h->sp;
+    set_first(P.sp, &first);
+    P.count = 0;
+    P.cap_rel_inf = max_t == BSX_T_INF ? 1 : 0;
+    P.max_t = max_t;
+    P.max_len = max_len;
+    P.ctr = h->d_ctr;
+    P.per_problem = per_problem ? d_pp.p : nullptr;
+    P.cc.journal = h->d_cc_journal.p;
+    P.cc.journal_count = h->d_cc_count.p;
+    P.cc.claims = h->d_cc_claims.p;
+    // cycles depend on the fixed nodes: with fixed-node variations they differ per problem
+    P.cc.enabled = (h->cache_enabled && h->sp.n_fv == 0) ? 1u : 0u;
+    P.cc.lds_slots = h->cache_lds_slots;
+    if (!h->fast_steps) h->fast_steps = kFastSteps;
+    P.fast_steps = h->fast_steps;
+    if (const char* sl = std::getenv("BSX_SERVICE_LANES")) P.pad = (uint32_t)std::atoi(sl);
+
+    MergedTable& merged = tot.merged;
+    auto account = [&](const AttractRun& r) {
+        tot.n_none += r.ctr.n_none; tot.steps_ref += r.ctr.steps_ref; tot.steps_exec += r.ctr.steps_exec;
+        tot.kernel_ms += r.ms; ++tot.launches; tot.limit_hits += r.ctr.step_limit_hits;
+    };
+
+    // Fast path: simple enumeration (no variations, 'any' nodes = nodes 0..a-1 or a few runs, a <= 64), cycle cache on.
+    // [discovery prefix with the detector] -> lean / pool kernel -> stragglers.
+    // (a short uniform warm-up is fine; its length enters the lean kernel's 32-bit sums of trajectory_l^2)
+    const bool simple = h->sp.n_any <= 64 && (h->sp.identity_any || h->sp.n_runs) && !h->sp.n_fv && !h->sp.n_pv && h->sp.tp_origin <= 200;
+    bool use_fast = P.cc.enabled && simple && h->fast_ok && count >= kFastMinProblems;
+    if (const char* e = std::getenv("BSX_LEAN")) use_fast = use_fast && std::atoi(e) != 0;      // tuning / test knob
+    if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] attract: count %llu%s cache %u identity %u n_any %u n_fv %u n_pv %u tp %u fast_ok %d -> lean path %d\n", (unsigned long long)count, (count >> 64) ? " (+2^64)" : "", P.cc.enabled, h->sp.identity_any, h->sp.n_any, h->sp.n_fv, h->sp.n_pv, h->sp.tp_origin, (int)h->fast_ok, (int)use_fast);
+    u128 done = 0;
+    if (use_fast) {
+        unsigned int known = 0;
+        if (h->journal_stale || h->h_journal.empty()) {
+            HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+            ++tot.syncs;
+        } else known = (unsigned int)h->h_journal.size();
+        if (known == 0) {
+            // Nothing cached yet: run the detector over a pseudo-random sample of the range (all digit
+            // positions vary), only to fill the cycle cache; its results are discarded and every problem
+            // is counted exactly once below.
+            const uint64_t m = (uint64_t)std::min<u128>(count, kDiscoverySample);
+            std::vector<uint32_t> sample(m);
+            for (uint64_t i = 0; i < m; ++i) {
+                uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;        // splitmix64 finaliser
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                sample[i] = (uint32_t)((z ^ (z >> 31)) % (uint64_t)std::min<u128>(count, (u128)1 << 32));
+            }
+            DevBuf<uint32_t> d_sample;
+            HIPCHK(h, d_sample.upload(sample));
+            AttractParams Q = P;
+            Q.count = m;
+            Q.offsets = d_sample.p;
+            Q.per_problem = nullptr;
+            AttractRun r;
+            if (int rc = launch_attract_pass(h, Q, kPassGeneral, d_log, nullptr, r, tot)) return rc;
+            tot.kernel_ms += r.ms; ++tot.launches; tot.steps_exec += r.ctr.steps_exec;
+            HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
+            ++tot.syncs;
+            if (known == 0) use_fast = false;           // nothing cacheable was found
+        }
+    }
+    // Lean kernel over tiles; what it cannot resolve (attractors not cached yet, long transients) goes
+    // through the detector right after each tile, which also teaches the cache for the next tile.
+    // The first tiles of a space are small probes: if most of their stragglers did end on a cached
+    // cycle state (just later than the FAST length), the FAST length is quadrupled for what follows.
+    // BSX_MERGE: 2 (default) class-pool kernel, 1 lean kernel with the in-lane sibling merge, 0 lean kernel
+    // without merging (A/B runs, tests)
+    const char* merge_env = std::getenv("BSX_MERGE");
+    int merge_mode = merge_env ? std::atoi(merge_env) : 2;
+    if (merge_mode == 2 && !h->pool_ok) merge_mode = 1;
+    const bool merge_lanes = merge_mode != 0;
+    // Lean / pool kernel over [done, seg_end) in tiles, then the detector over whatever the fast path gave up on.
+    auto run_tiles = [&](u128 seg_end) -> int {
+    while (use_fast && h->fast_ok && done < seg_end) {
+        const uint64_t tile = (uint64_t)std::min<u128>(seg_end - done, h->fast_calibrated ? kLeanTile : kProbeTile);
+        if (int rc = lean_mirror_slots(h, nullptr, &tot)) return rc;          // (refreshes h->h_journal if the detector ran since)
+        const unsigned int known_before_tile = (unsigned int)h->h_journal.size();
+        // straggler list: one word per problem, or up to three per class (base + 64-bit member mask) from the
+        // pool kernel -- probe tiles get room for every problem as a class of its own, big tiles for a third
+        // (more stragglers than that and the lean path is the wrong tool anyway)
+        const uint64_t strag_cap = h->fast_calibrated ? tile : 3 * tile;
+        DevBuf<uint32_t>& d_strag = h->d_strag;
+        if (d_strag.n < strag_cap) HIPCHK(h, d_strag.alloc(strag_cap));
+        AttractParams Q = P;
+        advance_first(Q.sp, first, (uint64_t)done);
+        Q.count = tile;
+        Q.fast_steps = h->fast_steps;
+        // the pool kernel first runs with member counts (classes of different groups merge too); that only works
+        // while nothing has to go back to the general kernel, so a tile that raises the abort flag is repeated
+        // with member masks.  Per-problem records need the masks from the start.
+        bool counting = merge_mode == 2 && !per_problem && (h->fast_calibrated || std::getenv("BSX_FORCE_COUNTING"));     // (knob: tests)
+        Q.merge = counting ? 2u : (merge_lanes ? 1u : 0u);
+        Q.per_problem = per_problem ? d_pp.p + (uint64_t)done : nullptr;
+        Q.stragglers = d_strag.p;
+        Q.stragglers_cap = strag_cap;
+        AttractRun r;
+        MergedTable tile_table;         // folded into `merged` only if the pass is accepted
+        if (int rc = launch_attract_pass(h, Q, merge_mode == 2 ? kPassPool : kPassLean, d_log, &tile_table, r, tot)) return rc;
+        if (counting && (r.ctr.straggler_overflow & 2u)) {
+            tot.kernel_ms += r.ms; ++tot.launches;              // dropped pass
+            counting = false;
+            Q.merge = 1u;
+            tile_table.clear();
+            r = AttractRun{};
+            if (int rc = launch_attract_pass(h, Q, kPassPool, d_log, &tile_table, r, tot)) return rc;
+        }
+        if (r.ctr.straggler_overflow) {
+            // more (group, mask) pairs than the list holds: the cache does not cover this space.  Drop the
+            // pass and give the rest of the range to the detector.
+            tot.kernel_ms += r.ms; ++tot.launches;
+            h->fast_ok = false;
+            break;
+        }
+        fold_table(merged, tile_table);
+        account(r);
+        uint64_t late = 0;
+        if (r.ctr.n_stragglers) {
+            uint64_t n_list = r.ctr.n_stragglers;
+            if (merge_lanes) {
+                // (group base, member mask words) records -> problem offsets, ascending
+                const size_t rec = merge_mode == 2 ? 3 : 2;     // the pool kernel's groups have 64 members
+                std::vector<uint32_t> pairs(rec * r.ctr.straggler_classes);
+                HIPCHK(h, hipMemcpy(pairs.data(), d_strag.p, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                ++tot.syncs;
+                std::vector<uint32_t> offs;
+                offs.reserve(n_list);
+                for (size_t c = 0; c + rec <= pairs.size(); c += rec)
+                    for (size_t wd = 1; wd < rec; ++wd)
+                        for (uint32_t left = pairs[c + wd]; left; left &= left - 1)
+                            offs.push_back(pairs[c] + (uint32_t)(32 * (wd - 1)) + (uint32_t)__builtin_ctz(left));
+                std::sort(offs.begin(), offs.end());
+                n_list = offs.size();
+                HIPCHK(h, hipMemcpy(d_strag.p, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+            AttractParams S = Q;
+            S.count = n_list;
+            S.offsets = d_strag.p;
+            S.stragglers = nullptr;
+            S.merge = 0;
+            AttractRun rs;
+            if (int rc = launch_attract_pass(h, S, kPassGeneral, d_log, &merged, rs, tot)) return rc;
+            account(rs);
+            late = rs.ctr.n_cache_resolved;
+        }
+        done += tile;
+        const bool many = r.ctr.n_stragglers > tile / 32;
+        if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] tile %llu: %llu stragglers, %llu of them ended on a cached cycle state; FAST length %u\n", (unsigned long long)tile, (unsigned long long)r.ctr.n_stragglers, (unsigned long long)late, h->fast_steps);
+        if (many && 2 * late >= r.ctr.n_stragglers && h->fast_steps < kFastStepsMax) {
+            h->fast_steps = std::min(kFastStepsMax, h->fast_steps * 4);     // long transients: give FAST more steps
+        } else {
+            if (tile >= kFastMinProblems) h->fast_calibrated = true;
+            if (r.ctr.n_stragglers > tile / 2) {
+                // Most of the tile went to the detector.  If that taught the cache new attractors (a region of the
+                // space nobody had visited), the next tile will do better; if not -- cycles too long to cache,
+                // or more attractors than the mirror holds -- the lean path is the wrong tool for this space.
+                unsigned int known_now = 0;
+                HIPCHK(h, hipMemcpy(&known_now, h->d_cc_count.p, sizeof(known_now), hipMemcpyDeviceToHost));
+                ++tot.syncs;
+                if (known_now <= known_before_tile) h->fast_ok = false;
+            }
+        }
+    }
+    // not (or no longer) a case for the lean path: the detector takes the rest, 2^32 problems per launch
+    while (done < seg_end) {
+        const uint64_t tile = (uint64_t)std::min<u128>(seg_end - done, kGeneralTile);
+        AttractParams Q = P;
+        const bsx_index at = index_plus(first, done, h->sp.n_any);
+        set_first(Q.sp, &at);
+        Q.count = tile;
+        Q.per_problem = per_problem ? d_pp.p + (uint64_t)done : nullptr;
+        AttractRun r;
+        if (int rc = launch_attract_pass(h, Q, kPassGeneral, d_log, &merged, r, tot)) return rc;
+        account(r);
+        done += tile;
+    }
+    return BSX_OK;
+    };
+
+    // ---- cube collapse: aligned blocks of >= 2^kCubeMinBits problems are enumerated by their relevant digits
+    // only (see build_cube).  Everything before the first / after the last such block goes through the tiles.
+    const char* cubes_env = std::getenv("BSX_CUBES");                     // "0": off (A/B runs, tests)
+    // (a warm-up under origin perturbations is fine: the first update still depends on the relevant digits only)
+    const bool cubes_ok = use_fast && merge_mode == 2 && !per_problem &&
+                          !(cubes_env && cubes_env[0] == '0') && h->sp.n_any >= kCubeMinBits;
+    if (cubes_ok) {
+        // [first, first + count) in digit values; blocks are aligned in the digit value, not in the offset
+        const u128 lo = first.init_digits[0], hi = lo + count;
+        const u128 unit = (u128)1 << kCubeMinBits;
+        u128 at = (lo + unit - 1) / unit * unit;
+        const u128 body_end = hi / unit * unit;
+        const CascadeEnv env{P, max_t, max_len, tot, d_log};
+        if (at < body_end) {
+            if (int rc = run_tiles(at - lo)) return rc;
+            while (at < body_end) {
+                uint32_t a_bits = kCubeMaxBits;
+                while (a_bits > kCubeMinBits && ((at & (((u128)1 << a_bits) - 1)) != 0 || at + ((u128)1 << a_bits) > body_end)) --a_bits;
+                a_bits = std::min(a_bits, h->sp.n_any);
+                bool collapsed = false;
+                // worth it when the block shrinks at least fourfold (otherwise the tiles do as well and keep member masks);
+                // a block that does not collapse is tried again in halves down to 2^32 problems, below that it is the tiles' turn
+                for (;;) {
+                    Cube c;
+                    build_cube(h, (uint64_t)at, a_bits, c);
+                    if (c.ok && c.rel.size() + 2 <= a_bits) if (int rc = run_cube(h, env, c, collapsed)) return rc;
+                    if (collapsed || a_bits <= 32) break;
+                    --a_bits;
+                }
+                const u128 block_end = (at - lo) + ((u128)1 << a_bits);
+                if (collapsed) done = block_end;
+                else if (int rc = run_tiles(block_end)) return rc;
+                at += (u128)1 << a_bits;
+            }
+        }
+    }
+    if (int rc = run_tiles(count)) return rc;
+
+    if (per_problem) {
+        const uint32_t nw = h->net.nw;
+        const uint64_t n = (uint64_t)count;
+        std::vector<ProblemRec32> pp(n);
+        HIPCHK(h, hipMemcpy(pp.data(), d_pp.p, n * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
+        for (uint64_t p = 0; p < n; ++p) {
+            bsx_problem_rec o{};
+            for (uint32_t w = 0; w < nw; ++w) o.key[w >> 1] |= (uint64_t)pp[p].key[w] << (32 * (w & 1));
+            o.length = pp[p].length; o.trajectory_l = pp[p].trajectory_l; o.found = pp[p].found;
+            per_problem[p] = o;
+        }
+    }
+    return BSX_OK;
+}
+
+// Spaces with more than 64 'any' nodes (e.g. a 128-node network with every node 'any'): only the 64 lowest initial-state
+// digits change inside 2^64 consecutive problems.  Such a stretch is run as the space in which exactly those are 'any'
+// and the higher digits belong to the origin state -- a plain space, which gets the lean / pool / cube paths.  (Same
+// network, same fixed nodes: the cycle cache carries over from stretch to stretch.)
+int attract_high_digits(bsx_handle h, const bsx_index& first, u128 count, uint64_t max_t, uint64_t max_len, Totals& tot) {
+    struct Restore {                    // the handle describes the whole space again, whatever happens below
+        bsx_handle h; DevSpace sp; std::vector<uint32_t> any;
+        ~Restore() { h->sp = sp; h->h_any = any; }
+    } restore{h, h->sp, h->h_any};
+    const DevSpace whole = h->sp;
+    const std::vector<uint32_t> any = h->h_any;
+    bool identity = true;
+    for (uint32_t j = 0; j < 64; ++j) identity = identity && any[j] == j;
+    bsx_index at = first;
+    while (count) {
+        const u128 room = ((u128)1 << 64) - at.init_digits[0];
+        const u128 seg = std::min(count, room);
+        DevSpace sv = whole;
+        for (uint32_t j = 64; j < whole.n_any; ++j)
+            if ((at.init_digits[j >> 6] >> (j & 63)) & 1ull) sv.origin[any[j] >> 5] |= 1u << (any[j] & 31);
+        sv.n_any = 64;
+        sv.identity_any = identity ? 1 : 0;
+        sv.n_runs = 0;
+        if (!identity) {
+            uint32_t j = 0, r = 0;
+            while (j < 64) {
+                uint32_t len = 1;
+                while (j + len < 64 && any[j + len] == any[j] + len && ((any[j] + len) >> 5) == (any[j] >> 5)) ++len;
+                sv.deposit[2 * r] = j | (any[j] >> 5) << 8 | (any[j] & 31u) << 16;
+                sv.deposit[2 * r + 1] = len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u;
+                ++r;
+                j += len;
+            }
+            sv.n_runs = r;                  // <= 64 = kMaxDepositRuns
+        }
+        h->sp = sv;
+        h->h_any.assign(any.begin(), any.begin() + 64);
+        bsx_index f{};
+        f.init_digits[0] = at.init_digits[0];
+        const int rc = attract_segment(h, f, seg, max_t, max_len, nullptr, tot);
+        h->sp = whole;
+        h->h_any = any;
+        if (rc) return rc;
+        at = index_plus(at, seg, whole.n_any);
+        count -= seg;
+    }
+    return BSX_OK;
+}
+
+// attract.py:262-302 semantics for every problem of [first, first + count): the body of both entry points.
+int attract_core(bsx_handle h, const bsx_index& first, u128 count, uint64_t max_t, uint64_t max_len, uint32_t cap,
+                 bsx_problem_rec* per_problem, Totals& tot) {
+    if (int rc = ensure_attractor_table(h, cap)) return rc;
+    const bool lean_off = std::getenv("BSX_LEAN") && std::atoi(std::getenv("BSX_LEAN")) == 0;
+    int rc;
+    if (h->sp.n_any > 64 && !h->sp.n_fv && !h->sp.n_pv && h->sp.tp_origin <= 200 && !per_problem && count >= (1u << 13) &&
+        h->cache_enabled && !lean_off)
+        rc = attract_high_digits(h, first, count, max_t, max_len, tot);
+    else
+        rc = attract_segment(h, first, count, max_t, max_len, per_problem, tot);
+    if (rc) return rc;
+    if (int rc2 = drain_attractor_table(h, tot.merged)) return rc2;
+    if (tot.merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
+    if (std::getenv("BSX_PROFILE")) {
+        std::fprintf(stderr, "[bsx] profile: passes: setup %.3f, enqueue %.3f, wait %.3f (kernels %.3f); %u host syncs\n",
+                     g_prof[0], g_prof[1], g_prof[2], g_prof[3], tot.syncs);
+        for (double& v : g_prof) v = 0;
+    }
+    return BSX_OK;
+}
+
+int attract_preamble(bsx_handle h, const bsx_index* first, u128 count, uint64_t max_t) {
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    return BSX_OK;
+}
+
+bool fgraph_knob(bsx_handle h) {            // knob: route eligible calls through the functional-graph mode
+    const char* fg = std::getenv("BSX_FGRAPH");
+    return fg && fg[0] == '1' && h->n_nodes <= 32 && h->sp.n_any == h->n_nodes && h->sp.identity_any && !h->sp.n_fv &&
+           !h->sp.n_pv && h->lut_mode != 2;
+}
+
+}  // namespace
+
+extern "C" int bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                               uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
+                               uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
+    if (int rc = attract_preamble(h, first, count, max_t)) return rc;
+    const double t_begin = now_ms();
+    *n_out = 0;
+    if (n_no_attractor) *n_no_attractor = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+    if (!per_problem && fgraph_knob(h))
+        return bsx_run_attract_fgraph(h, first, count, max_t, max_len, table, cap, n_out, n_no_attractor, stats);
+    if (per_problem && count > (1ull << 32)) return fail(h, BSX_ERR_INVALID, "at most 2^32 problems per call with per-problem records");
+
+    Totals tot;
+    if (int rc = attract_core(h, *first, count, max_t, max_len, cap, per_problem, tot)) return rc;
+    uint32_t i = 0;
+    for (auto& kv : tot.merged) {
+        const WideRec& w = kv.second;
+        if ((w.count >> 64) != 0 || !w.sum_l.fits(1) || !w.sum_l2.fits(2))
+            return fail(h, BSX_ERR_RANGE_TOO_LARGE, "an attractor's count / sum of trajectory lengths exceeds the 64-bit fields of bsx_attr_rec: use bsx_run_attract2");
+        bsx_attr_rec& a = table[i++];
+        for (int k = 0; k < BSX_MAX_WORDS; ++k) a.key[k] = w.key[k];
+        a.length = w.length; a.count = (uint64_t)w.count; a.sum_l = w.sum_l.w[0];
+        a.sum_l2_lo = w.sum_l2.w[0]; a.sum_l2_hi = w.sum_l2.w[1];
+    }
+    *n_out = i;
+    if (n_no_attractor) *n_no_attractor = (uint64_t)tot.n_none;
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = (uint64_t)tot.steps_ref;           // (count < 2^64 and trajectories < 2^31: may wrap only beyond 2^33 x ... problems; bsx_run_attract2 is wide)
+        stats->executed_steps = tot.steps_exec;
+        stats->kernel_ms = tot.kernel_ms;
+        stats->kernel_launches = tot.launches;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    if (tot.limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit without closing its cycle");
+    return BSX_OK;
+}
+
+extern "C" int bsx_run_attract2(bsx_handle h, bsx_u128 first_flat, bsx_u128 count_flat, uint64_t max_t, uint64_t max_len,
+                                bsx_attr_rec2* table, uint32_t cap, uint32_t* n_out, bsx_u128* n_no_attractor,
+                                bsx_stats2* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    // flat index I = init_digits + variant * 2^n_any (batching.py:212-229)
+    const u128 I = ((u128)first_flat.hi << 64) | first_flat.lo, count = ((u128)count_flat.hi << 64) | count_flat.lo;
+    const uint32_t n_any = h->sp.n_any;
+    bsx_index first{};
+    if (n_any >= 128) { first.init_digits[0] = (uint64_t)I; first.init_digits[1] = (uint64_t)(I >> 64); }
+    else {
+        const u128 low = I & (((u128)1 << n_any) - 1), variant = I >> n_any;
+        if ((variant >> 64) != 0) return fail(h, BSX_ERR_UNSUPPORTED, "variant part of the problem index exceeds 64 bits");
+        first.init_digits[0] = (uint64_t)low; first.init_digits[1] = (uint64_t)(low >> 64);
+        first.variant = (uint64_t)variant;
+    }
+    if (int rc = attract_preamble(h, &first, count, max_t)) return rc;
+    const double t_begin = now_ms();
+    *n_out = 0;
+    if (n_no_attractor) *n_no_attractor = bsx_u128{0, 0};
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+
+    Totals tot;
+    if (int rc = attract_core(h, first, count, max_t, max_len, cap, nullptr, tot)) return rc;
+    uint32_t i = 0;
+    for (auto& kv : tot.merged) {
+        const WideRec& w = kv.second;
+        bsx_attr_rec2& a = table[i++];
+        for (int k = 0; k < BSX_MAX_WORDS; ++k) a.key[k] = w.key[k];
+        a.length = w.length;
+        a.count.lo = (uint64_t)w.count; a.count.hi = (uint64_t)(w.count >> 64);
+        for (int k = 0; k < 3; ++k) a.sum_l[k] = w.sum_l.w[k];
+        for (int k = 0; k < 4; ++k) a.sum_l2[k] = w.sum_l2.w[k];
+    }
+    *n_out = i;
+    if (n_no_attractor) { n_no_attractor->lo = (uint64_t)tot.n_none; n_no_attractor->hi = (uint64_t)(tot.n_none >> 64); }
+    if (stats) {
+        stats->problems = count_flat;
+        stats->state_steps.lo = (uint64_t)tot.steps_ref; stats->state_steps.hi = (uint64_t)(tot.steps_ref >> 64);
+        stats->executed_steps = tot.steps_exec;
+        stats->kernel_ms = tot.kernel_ms;
+        stats->dominant_ms = tot.dominant_ms;
+        stats->dominant_executed_steps = tot.dominant_exec;
+        stats->dominant_launches = tot.dominant_launches;
+        stats->kernel_launches = tot.launches;
+        stats->host_syncs = tot.syncs;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    if (tot.limit_hits) return fail(h, BSX_ERR_STEP_LIMIT, "a trajectory reached the internal step limit without closing its cycle");
+    return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Functional-graph mode (bsx_fgraph.hip): attract over [first, first + count) of a space whose n <= 32 nodes
+// are all 'any', from N = 2^n-sized arrays.  Same results as bsx_run_attract.
+extern "C" int bsx_run_attract_fgraph(bsx_handle h, const bsx_index* first, uint64_t count, uint64_t max_t,
+                                      uint64_t max_len, bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
+                                      uint64_t* n_no_attractor, bsx_stats* stats) {
+    if (!h) return BSX_ERR_INVALID;
+    if (!h->have_net || !h->have_space) return fail(h, BSX_ERR_STATE, "network / problem space not set");
+    if (!table || !n_out) return fail(h, BSX_ERR_INVALID, "table / n_out is null");
+    if (int rc = check_range(h, first, count)) return rc;
+    if (int rc = check_max_t(h, max_t)) return rc;
+    const uint32_t n = h->n_nodes;
+    if (n > 32 || h->sp.n_any != n || !h->sp.identity_any || h->sp.n_fv || h->sp.n_pv || h->lut_mode == 2)
+        return fail(h, BSX_ERR_UNSUPPORTED, "functional-graph mode needs n <= 32 nodes, all of them 'any', and no variations");
+    const uint32_t tp = h->sp.tp_origin;                    // origin perturbations: the search starts at s(T_p)
+    const double t_begin = now_ms();
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_out = 0;
+    if (n_no_attractor) *n_no_attractor = 0;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (count == 0) return BSX_OK;
+    if (h->table_dirty) { MergedTable stale; if (int rc = drain_attractor_table(h, stale)) return rc; }
+    {
+        uint64_t want = 1ull << 16;
+        while (want < 2 * (uint64_t)cap) want *= 2;
+        if (h->table_slots < want) {
+            HIPCHK(h, h->d_table.alloc(want));
+            HIPCHK(h, hipMemset(h->d_table.p, 0, want * sizeof(LogRec)));
+            h->table_slots = want;
+        }
+    }
+    const uint64_t N = 1ull << n;
+    const uint32_t cus = (uint32_t)h->prop.multiProcessorCount;
+    const bool capped = max_t != BSX_T_INF;
+    const uint64_t cap_rel = capped ? max_t - tp : UINT64_MAX;     // found iff mu + lambda <= max_t - T_p (S7)
+    // doubling rounds: 2^rounds must reach every transient that can still be "found"; without a cap, every
+    // transient (mu < N)
+    uint32_t rounds = 0;
+    while (rounds < n && (!capped || (1ull << rounds) <= cap_rel)) ++rounds;
+    const uint64_t walk_cap = capped ? std::max<uint64_t>(cap_rel, 1) : (1ull << 22);
+    const uint32_t cand_cap = 1u << 22;
+
+    DevBuf<uint32_t>& succ = h->d_fg_a;
+    DevBuf<uint32_t>& ja = h->d_fg_b;
+    DevBuf<uint32_t>& jb = h->d_fg_c;
+    HIPCHK(h, succ.reserve(N));
+    HIPCHK(h, ja.reserve(std::max<uint64_t>(N, 1024)));         // phase D reuses ja + jb as one array of N pairs
+    HIPCHK(h, jb.reserve(std::max<uint64_t>(N, 1024)));
+    DevBuf<uint32_t> d_bits, d_cand;
+    DevBuf<unsigned int> d_small;       // [0] candidate cursor, [1] cyclic, [2] open, [3] changed
+    HIPCHK(h, d_bits.alloc((N + 31) / 32));
+    HIPCHK(h, hipMemsetAsync(d_bits.p, 0, ((N + 31) / 32) * 4, h->stream));
+    HIPCHK(h, d_cand.alloc(cand_cap));
+    HIPCHK(h, d_small.alloc(4));
+    HIPCHK(h, hipMemsetAsync(d_small.p, 0, 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
+
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    uint32_t launches = 0;
+    // A: successor array
+    {
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 4, (N + kBlock - 1) / kBlock));
+        HIPCHK(h, launch_fg_succ((int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, h->net, h->sp, N, succ.p, 0));
+        ++launches;
+        if (tp) {
+            HIPCHK(h, h->d_fg_warm.reserve(N));
+            HIPCHK(h, launch_fg_succ((int)h->net.k_mux, h->lut_mode, dim3((uint32_t)blocks), h->shmem, h->stream, h->net, h->sp, N, h->d_fg_warm.p, tp));
+            ++launches;
+        }
+    }
+    // B: landing points f^(2^rounds)(s)
+    const uint32_t* land = succ.p;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t* out = (r & 1) ? jb.p : ja.p;
+        HIPCHK(h, launch_fg_double(land, out, N, cus, h->stream));
+        land = out;
+        ++launches;
+    }
+    // C: candidates -> cycle states
+    HIPCHK(h, launch_fg_mark(land, N, d_bits.p, cus, h->stream));
+    HIPCHK(h, launch_fg_collect(d_bits.p, (N + 31) / 32, d_cand.p, cand_cap, d_small.p, cus, h->stream));
+    launches += 2;
+    unsigned int small[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(small, d_small.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint32_t n_cand = small[0];
+    if (n_cand > cand_cap) return fail(h, BSX_ERR_UNSUPPORTED, "functional-graph mode: more than 2^22 distinct landing points (use the trajectory path)");
+    uint32_t cyc_slots = 1024;
+    while (cyc_slots < 4 * (uint64_t)n_cand) cyc_slots *= 2;
+    DevBuf<unsigned char> d_cyc;
+    HIPCHK(h, d_cyc.alloc((size_t)(cyc_slots + 1) * fg_cyc_entry_bytes()));
+    HIPCHK(h, hipMemsetAsync(d_cyc.p, 0, (size_t)(cyc_slots + 1) * fg_cyc_entry_bytes(), h->stream));
+    HIPCHK(h, launch_fg_cycles(succ.p, d_cand.p, n_cand, walk_cap, d_cyc.p, cyc_slots - 1, d_small.p + 1, d_small.p + 2, h->stream));
+    ++launches;
+    HIPCHK(h, hipMemcpyAsync(small, d_small.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!capped && small[2]) return fail(h, BSX_ERR_STEP_LIMIT, "functional-graph mode: a cycle longer than 2^22 states (no time cap given)");
+    // D: (entry state, mu) by in-place pointer jumping; pairs live in ja..jb (N x 8 bytes)
+    if ((const void*)(ja.p + N) != (const void*)jb.p) {
+        // the two halves are separate allocations: use a dedicated pair array instead
+        HIPCHK(h, h->d_fg_pair.reserve(N));
+    }
+    unsigned long long* pair = ((const void*)(ja.p + N) == (const void*)jb.p) ? reinterpret_cast<unsigned long long*>(ja.p) : h->d_fg_pair.p;
+    HIPCHK(h, launch_fg_pair_init(succ.p, d_cyc.p, cyc_slots - 1, pair, N, cus, h->stream));
+    ++launches;
+    const uint32_t d_cap = capped ? (uint32_t)std::min<uint64_t>(cap_rel, 0xFFFFFFFEull) : 0xFFFFFFFEu;
+    for (uint32_t r = 0; r < n + 2; ++r) {
+        HIPCHK(h, hipMemsetAsync(d_small.p + 3, 0, 4, h->stream));
+        HIPCHK(h, launch_fg_pair_jump(pair, N, d_cap, d_small.p + 3, cus, h->stream));
+        ++launches;
+        HIPCHK(h, hipMemcpyAsync(small, d_small.p, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!small[3]) break;
+    }
+    // E: aggregate the requested problems
+    AttractParams P{};
+    P.ctr = h->d_ctr;
+    P.table = h->d_table.p;
+    P.table_mask = h->table_slots - 1;
+    const uint64_t first_state = first->init_digits[0];
+    HIPCHK(h, launch_fg_aggregate(pair, d_cyc.p, cyc_slots - 1, tp ? h->d_fg_warm.p : nullptr, tp, first_state, count, cap_rel, max_len,
+                                  capped ? max_t : 0, P, cus, h->stream));
+    ++launches;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    Counters ctr{};
+    HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->table_dirty = true;
+    if (ctr.table_overflow) { MergedTable junk; (void)drain_attractor_table(h, junk); return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity"); }
+    MergedTable merged;
+    if (int rc = drain_attractor_table(h, merged)) return rc;
+    if (merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
+    uint32_t i = 0;
+    for (auto& kv : merged) {                       // (at most 2^32 problems: every sum fits the record)
+        const WideRec& w = kv.second;
+        bsx_attr_rec& a = table[i++];
+        for (int k = 0; k < BSX_MAX_WORDS; ++k) a.key[k] = w.key[k];
+        a.length = w.length; a.count = (uint64_t)w.count; a.sum_l = w.sum_l.w[0];
+        a.sum_l2_lo = w.sum_l2.w[0]; a.sum_l2_hi = w.sum_l2.w[1];
+    }
+    *n_out = i;
+    if (n_no_attractor) *n_no_attractor = ctr.n_none;
+    if (stats) {
+        stats->problems = count;
+        stats->state_steps = ctr.steps_ref;
+        stats->executed_steps = N * (1 + (uint64_t)tp);     // one network update per state of the space (+ the warm-up map)
+        stats->kernel_ms = ms;
+        stats->kernel_launches = launches;
+        stats->total_ms = now_ms() - t_begin;
+    }
+    return BSX_OK;
+}

@@ -7,7 +7,10 @@ namespace bsx {
 constexpr int kWave = 64;
 constexpr int kBlock = 512;                 // 8 waves per workgroup share one LUT + cache mirror in LDS
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kPoolBlockThreads = 768;      // the pool kernel's workgroup (bsx_pool.hip)
+constexpr int kPoolBlockThreads = 768;      // the pool kernel's workgroup (bsx_pool_kernel.h)
+constexpr uint32_t kPoolCap = 112;          // ... classes per wave (ring buffer; > 64 + what a fresh stage leaves)
+constexpr uint32_t kPoolSlots = 128;        // ... merge slots per wave (one-byte lane ids; 256 slots: 2 % fewer updates, not worth 1.5 KiB of LDS)
+constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // ... ring record: state, group base, members lo/hi, time
 constexpr int kMaxW32 = 8;                  // 32-bit words per state (n <= 256)
 constexpr int kMaxMuxK = 6;                 // nodes with more predecessors take the "wide" path
 constexpr int kTableSlots = 64;             // per-wave attractor table: one slot per lane (registers)
@@ -100,6 +103,10 @@ struct alignas(256) Counters {   // zeroed before every launch (a multiple of 25
     unsigned long long acc_cnt[64], acc_sl[64], acc_sl2_lo[64], acc_sl2_hi[64];
     unsigned int acc_len[64];
     unsigned int acc_key[64][kMaxW32];
+    // ... in units of 2^unit_shift problems (the host scales them).  A member that is a cycle state itself (mu = 0, at most one
+    // per class) is not a whole unit: its class is booked at mu = 1 and these signed, ABSOLUTE sums move the one problem
+    unsigned long long fix_cnt[64], fix_sl[64], fix_sl2[64];   // two's complement
+    unsigned long long fix_none, fix_ref, fix_capfail;
     unsigned long long near_classes;    // deep cube pass: classes whose common state F^depth is a cycle state (listed, see AttractParams::near)
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic
@@ -143,6 +150,16 @@ struct CycleCache {
     uint32_t enabled;
     uint32_t lds_slots;         // power of two; the LDS mirror holds at most lds_slots / 2 states
 };
+
+// Hand-over between two levels of a cube cascade, written by k_compact_near, read by the next level's launch.
+struct LevelDesc {
+    unsigned long long n_entries;   // classes listed by the level above (packed list)
+    unsigned int abort;             // a segment of the level above overflowed: the list is incomplete, the block is redone shallower
+    unsigned int pad;
+};
+constexpr uint32_t kMaxCubeLevels = 16;     // levels of one cascade (= Counters blocks / descriptors per call)
+constexpr size_t kLevelDescBytes = 512;     // the descriptors' share of the counter buffer (a multiple of the Counters alignment)
+static_assert(sizeof(LevelDesc) * (kMaxCubeLevels + 1) <= kLevelDescBytes, "descriptor block");
 
 struct AttractParams {
     DevNet net;
@@ -207,6 +224,10 @@ struct AttractParams {
     uint32_t* mirror_out;
     // general kernel, discovery from explicit states: work item i starts at states[i * nw ..] (no enumeration)
     const uint32_t* states;
+    // Chained cascade (DESIGN.md "levels chained on the device"): a lower level's launch is enqueued before the level
+    // above has run, so its number of work items comes from the device: count = level_in->n_entries << entry_shift
+    // (nothing to do when that is 0 or level_in->abort is set), and the split over the waves is derived from it there.
+    const LevelDesc* level_in;
 };
 
 // Cube collapse, ordering heuristic: how long does a flip of each relevant digit stay visible?  One thread per

@@ -82,6 +82,7 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_near_seg;   // deep cube passes: classes listed for the level below, one segment per workgroup,
     bsx::DevBuf<uint32_t> d_near_counts;    // the segments' fill counts,
     bsx::DevBuf<uint32_t> d_near_list;  // and the packed list the next level reads
+    bsx::DevBuf<uint32_t> d_unres;      // cascade: unresolved classes per level (state, t, member count)
     uint32_t life_cache[64] = {};       // cube passes: k_digit_lifetimes per digit, measured on the first block that needed it
     uint64_t life_valid = 0;            // (an ordering heuristic: later blocks of the problem reuse it)
     uint32_t cube_depth_cap = 0;        // 0 = no experience yet; else the deepest level that paid off on this problem
@@ -94,7 +95,6 @@ struct bsx_engine {
     std::vector<uint32_t> h_sched;      // origin perturbations (t, node, value), sorted by t
     std::vector<uint32_t> h_any;        // 'any' nodes in digit order (cube collapse: relevant-digit analysis)
     std::vector<uint32_t> h_fv;         // fixed-node variations (node, range) in digit order
-    bool in_low_digit_call = false;     // bsx_run_attract is running a > 64-digit space as its 64 lowest digits
 
     // problem space
     bool have_space = false;
@@ -104,9 +104,18 @@ struct bsx_engine {
     bsx::DevSpace sp{};
     bsx::DevBuf<uint32_t> d_any, d_fv, d_pv, d_set, d_clr;
 
-    bsx::DevBuf<bsx::Counters> d_ctr;
-    bool ctr_zeroed = false;            // d_ctr has been cleared on the device already (by k_compact_near): the next pass skips its memset
-    bsx::Counters* h_ctr = nullptr;     // pinned landing buffer for the counters of a pass
+    // counters: one block for a single pass, one per level for a cube cascade, which is enqueued as a whole and read
+    // back once.  The hand-over descriptors of the levels (k_compact_near -> next launch) sit right in front of block 0
+    // so that one fill clears both.  h_ctr: pinned host buffer of the same shape; a cascade's last kernel (k_publish)
+    // stores the blocks there and then the sequence number of the call into h_flag, which the host spins on -- the
+    // wake-up of a blocking wait was a third of a 0.3 ms call.
+    bsx::DevBuf<unsigned char> d_ctr_raw;
+    bsx::LevelDesc* d_level = nullptr;      // [kMaxCubeLevels + 1]
+    bsx::Counters* d_ctr = nullptr;         // [kMaxCubeLevels]
+    bsx::Counters* h_ctr = nullptr;
+    volatile uint32_t* h_flag = nullptr;    // (behind h_ctr in the same pinned allocation)
+    uint32_t flag_seq = 0;
+    hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;    // around the top-level (dominant) launch of a cascade
 
     // functional-graph mode (bsx_fgraph.hip): N-sized arrays, kept between calls (grow-only)
     bsx::DevBuf<uint32_t> d_fg_a, d_fg_b, d_fg_c, d_fg_warm;

@@ -9,19 +9,26 @@ simulation problems are independent, so rank r simply takes the contiguous index
 
 Two planes:
   control  `Bootstrap`: a TCP star on the launcher's MASTER_ADDR (rank 0 is the hub).  It carries the
-           128-byte ncclUniqueId from rank 0 to the others, barriers, the record counts that size the
-           all-gather, scalar reductions of run statistics, and it is how a rank learns that a peer has
-           died (closed socket) instead of blocking in a collective for ever.  Pure Python, no MPI, no
-           tensor framework.  Rendezvous: rank 0 listens on an ephemeral port and publishes it in a file named
-           after MASTER_PORT and the launcher's pid (the port itself belongs to the launcher's store).
+           128-byte ncclUniqueId from rank 0 to the others, barriers, scalar reductions of run statistics
+           (JSON: ints of any size, floats, bools, strings -- nothing executable is ever deserialised), and it
+           is how a rank learns that a peer has died (closed socket) instead of blocking in a collective for
+           ever.  Pure Python, no MPI, no tensor framework.
+           Rendezvous, ONE NODE (the default, what torch.distributed.run / the driver gives): rank 0 listens on
+           an ephemeral port and publishes it, with a 32-byte secret, in a 0600 file in the local temp directory
+           named after MASTER_ADDR / MASTER_PORT / the launcher's run id (the port itself belongs to the
+           launcher's store).  SEVERAL NODES or ranks without a common temp directory (mpirun, srun, separate
+           shells): set BSX_CONTROL_PORT (rank 0 listens there, no file) and BSX_RDZV_KEY (the shared secret)
+           on every rank.  Either way a peer must answer an HMAC-SHA256 challenge keyed by the secret before
+           anything it sends is looked at, and frames are capped at 1 GiB.
   data     RCCL, once `attach_engine` has built the communicator.  Without an engine the data collectives
            refuse to run unless BSX_DIST_BACKEND=socket explicitly routes them through the control
            plane -- that is for CPU-only tests and for rehearsing several ranks on ONE GPU (RCCL wants
            one device per rank); it is never picked silently.
 """
 import hashlib
+import hmac
+import json
 import os
-import pickle
 import socket
 import struct
 import tempfile
@@ -31,7 +38,8 @@ import numpy as np
 
 from . import _lib
 
-_MAGIC = b'BSX1'
+_MAGIC = b'BSX2'
+_MAX_FRAME = 1 << 30
 
 
 class PeerLost(RuntimeError):
@@ -55,31 +63,41 @@ def _send_frame(sock, payload):
 
 def _recv_frame(sock):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if n > _MAX_FRAME:
+        raise PeerLost('control frame of {} bytes exceeds the limit'.format(n))
     return _recv_exact(sock, n)
+
+
+def _mac(secret, *parts):
+    return hmac.new(secret, b'|'.join(parts), hashlib.sha256).digest()
 
 
 class Bootstrap:
     """Control plane of a job: all-gather of small byte strings over a TCP star (rank 0 = hub)."""
 
-    def __init__(self, rank, world, addr, key, timeout=300.0):
+    def __init__(self, rank, world, addr, key, timeout=300.0, port=None):
         self.rank, self.world = rank, world
         self._peers = {}            # hub: rank -> socket
         self._hub = None            # others: socket to rank 0
         self._listener = None
         digest = hashlib.sha256(key.encode()).digest()
         directory = os.environ.get('BSX_RDZV_DIR', tempfile.gettempdir())
-        self._path = os.path.join(directory, 'bsx_rdzv_{}_{}'.format(os.getuid(), digest[:8].hex()))
+        self._path = None if port else os.path.join(directory, 'bsx_rdzv_{}_{}'.format(os.getuid(), digest[:8].hex()))
         deadline = time.monotonic() + timeout
+        who = struct.pack('<QQ', rank, world)
         if rank == 0:
             self._listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             self._listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            self._listener.bind((addr, 0))
+            self._listener.bind((addr, port or 0))
             self._listener.listen(world)
-            nonce = os.urandom(8)
-            tmp = '{}.{}'.format(self._path, os.getpid())
-            with open(tmp, 'wb') as f:
-                f.write(struct.pack('<I', self._listener.getsockname()[1]) + nonce)
-            os.replace(tmp, self._path)         # atomic: readers see the old file or the whole new one
+            # the secret: random and handed over through the 0600 file (one node), or derived from the shared key
+            secret = digest if port else os.urandom(32)
+            if not port:
+                tmp = '{}.{}'.format(self._path, os.getpid())
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+                with os.fdopen(fd, 'wb') as f:
+                    f.write(struct.pack('<I', self._listener.getsockname()[1]) + secret)
+                os.replace(tmp, self._path)     # atomic: readers see the old file or the whole new one
             while len(self._peers) < world - 1:
                 self._listener.settimeout(max(0.1, deadline - time.monotonic()))
                 try:
@@ -89,13 +107,17 @@ class Bootstrap:
                         len(self._peers) + 1, world, timeout))
                 conn.settimeout(10.0)
                 try:
-                    hello = _recv_exact(conn, 4 + 8 + 8 + 8)
-                    peer, pworld = struct.unpack('<QQ', hello[12:])
-                    if hello[:4] != _MAGIC or hello[4:12] != digest[8:16] or pworld != world or not 0 < peer < world \
-                            or peer in self._peers:
+                    hello = _recv_exact(conn, 4 + 16)
+                    peer, pworld = struct.unpack('<QQ', hello[4:])
+                    if hello[:4] != _MAGIC or pworld != world or not 0 < peer < world or peer in self._peers:
                         raise ValueError
-                    conn.sendall(nonce)
-                except (ValueError, PeerLost, OSError):
+                    challenge = os.urandom(16)
+                    conn.sendall(challenge)
+                    # the peer proves that it holds the secret (it read the file / knows the key) ...
+                    if not hmac.compare_digest(_recv_exact(conn, 32), _mac(secret, b'peer', challenge, hello[4:])):
+                        raise ValueError
+                    conn.sendall(_mac(secret, b'hub', challenge))       # ... and so does the hub
+                except (ValueError, PeerLost, OSError, struct.error):
                     conn.close()                # not one of ours (stale client, port scanner)
                     continue
                 conn.settimeout(None)
@@ -104,21 +126,32 @@ class Bootstrap:
         else:
             while self._hub is None:
                 if time.monotonic() > deadline:
-                    raise PeerLost('rank 0 did not publish its control port within {} s ({})'.format(timeout, self._path))
+                    raise PeerLost('rank 0 did not {} within {} s'.format(
+                        'accept on control port {}'.format(port) if port else 'publish its control port ({})'.format(self._path), timeout))
+                conn = None
                 try:
-                    with open(self._path, 'rb') as f:
-                        blob = f.read()
-                    (port,), nonce = struct.unpack('<I', blob[:4]), blob[4:12]
-                    conn = socket.create_connection((addr, port), timeout=5.0)
-                    conn.sendall(_MAGIC + digest[8:16] + struct.pack('<QQ', rank, world))
-                    if _recv_exact(conn, 8) != nonce:
+                    if port:
+                        to, secret = port, digest
+                    else:
+                        with open(self._path, 'rb') as f:
+                            blob = f.read()
+                        (to,), secret = struct.unpack('<I', blob[:4]), blob[4:36]
+                        if len(secret) != 32:
+                            raise ValueError
+                    conn = socket.create_connection((addr, to), timeout=5.0)
+                    conn.sendall(_MAGIC + who)
+                    challenge = _recv_exact(conn, 16)
+                    conn.sendall(_mac(secret, b'peer', challenge, who))
+                    if not hmac.compare_digest(_recv_exact(conn, 32), _mac(secret, b'hub', challenge)):
                         raise ValueError
                     conn.settimeout(None)
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     self._hub = conn
                 except (OSError, ValueError, struct.error, PeerLost):
+                    if conn is not None:
+                        conn.close()
                     time.sleep(0.05)            # file not there yet, or left over from an earlier job
-        if rank == 0:
+        if rank == 0 and self._path:
             try:
                 os.unlink(self._path)           # everyone is connected; the file has done its job
             except OSError:
@@ -156,6 +189,15 @@ class Bootstrap:
         self._peers, self._hub, self._listener = {}, None, None
 
 
+def _dumps(obj):
+    """Control-plane values: None, bools, ints of any size, floats, strings and lists of those -- as JSON."""
+    return json.dumps(obj).encode()
+
+
+def _loads(raw):
+    return json.loads(raw.decode())
+
+
 class Comm:
     """World of size 1 unless initialised from the launcher's environment (RANK / WORLD_SIZE / MASTER_*)."""
 
@@ -180,10 +222,13 @@ class Comm:
         if c.backend not in ('rccl', 'socket'):
             raise ValueError('BSX_DIST_BACKEND must be "rccl" or "socket", not "{}"'.format(c.backend))
         addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
-        key = os.environ.get('BSX_RDZV_KEY') or '{}|{}|{}|{}|{}'.format(
+        key = os.environ.get('BSX_RDZV_KEY') or '{}|{}|{}|{}'.format(
             addr, os.environ.get('MASTER_PORT', ''), os.environ.get('TORCHELASTIC_RUN_ID', ''),
-            os.environ.get('TORCHELASTIC_RESTART_COUNT', ''), os.getppid())
-        c._boot = Bootstrap(c.rank, world, addr, key, float(os.environ.get('BSX_RDZV_TIMEOUT', '300')))
+            os.environ.get('TORCHELASTIC_RESTART_COUNT', ''))
+        port = int(os.environ.get('BSX_CONTROL_PORT', '0')) or None
+        if port and not os.environ.get('BSX_RDZV_KEY'):
+            raise ValueError('BSX_CONTROL_PORT needs BSX_RDZV_KEY (the secret the ranks share) as well')
+        c._boot = Bootstrap(c.rank, world, addr, key, float(os.environ.get('BSX_RDZV_TIMEOUT', '300')), port)
         return c
 
     @property
@@ -221,12 +266,12 @@ class Comm:
         """Python object of `root` on every rank (control plane: small things such as the output directory)."""
         if self._boot is None:
             return obj
-        return pickle.loads(self._boot.allgather(pickle.dumps(obj) if self.rank == root else b'')[root])
+        return _loads(self._boot.allgather(_dumps(obj) if self.rank == root else b'')[root])
 
     def allgather_obj(self, obj):
         if self._boot is None:
             return [obj]
-        return [pickle.loads(p) for p in self._boot.allgather(pickle.dumps(obj))]
+        return [_loads(p) for p in self._boot.allgather(_dumps(obj))]
 
     def allreduce_max(self, value):
         return max(float(v) for v in self.allgather_obj(float(value)))
@@ -251,24 +296,34 @@ class Comm:
         parts = self._boot.allgather(raw.tobytes())
         return np.frombuffer(b''.join(parts), np.uint8).reshape(self.world, per_rank)
 
-    def allgather_records(self, records):
+    def allgather_records(self, records, slots=None):
         """
-        All-gather a 1-D numpy structured array (e.g. _lib.ATTR_REC) -> list of per-rank arrays.
-        The counts go over the control plane first, so the data plane is exactly ONE all-gather of
-        max(count) record slots per rank (none at all if nobody has a record).
+        All-gather a 1-D numpy structured array (e.g. _lib.ATTR_REC2) -> list of per-rank arrays, in ONE data-plane
+        collective with nothing on the control plane: every rank sends a 16-byte header (its record count) followed
+        by `slots` record slots (default 1024, the size is the same on every rank by construction).  Only if some
+        rank had more records than slots -- every rank sees that in the headers -- the collective is repeated with
+        the largest count.
         """
         if self._boot is None:
             return [records]
-        counts = self.allgather_obj(len(records))
-        cap = max(counts)
         item = records.dtype.itemsize
-        if cap == 0:
-            return [np.zeros(0, records.dtype) for _ in counts]
-        buf = np.zeros(cap * item, np.uint8)
         raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
-        buf[:raw.size] = raw
-        host = self._allgather_bytes(buf, cap * item)
-        return [np.frombuffer(host[r, :c * item].tobytes(), dtype=records.dtype) for r, c in enumerate(counts)]
+        cap = max(1, int(slots or 1024))
+        for _ in range(2):
+            buf = np.zeros(16 + cap * item, np.uint8)
+            buf[:16] = np.frombuffer(struct.pack('<QQ', len(records), item), np.uint8)
+            buf[16:16 + min(raw.size, cap * item)] = raw[:cap * item]
+            host = self._allgather_bytes(buf, buf.size)
+            counts = []
+            for r in range(self.world):
+                n, it = struct.unpack('<QQ', host[r, :16].tobytes())
+                if it != item:
+                    raise RuntimeError('rank {} sent records of {} bytes, expected {}'.format(r, it, item))
+                counts.append(n)
+            if max(counts) <= cap:
+                return [np.frombuffer(host[r, 16:16 + c * item].tobytes(), dtype=records.dtype) for r, c in enumerate(counts)]
+            cap = max(counts)
+        raise RuntimeError('record counts changed between two collectives')
 
     def gather_concat(self, array):
         """All-gather a numpy array along axis 0 (rank order = index order for range partitions)."""
@@ -293,7 +348,19 @@ class Comm:
             self._boot.close()
             self._boot = None
 
-    abort = shutdown            # closing the control connection is what tells the peers
+    def abort(self):
+        """A rank that failed: the control connection goes FIRST -- that is what wakes the peers (their next control
+        operation raises PeerLost) -- and only then the communicator, whose teardown may block behind a collective
+        that will never complete."""
+        if self._boot is not None:
+            self._boot.close()
+            self._boot = None
+        if self._engine is not None:
+            try:
+                self._engine.comm_destroy()
+            except Exception:   # noqa: BLE001
+                pass
+            self._engine = None
 
 
 def partition(n_problems, world, rank):

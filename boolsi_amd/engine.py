@@ -82,6 +82,12 @@ class Engine:
         self._check(self._lib.bsx_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)))
         return {'name': name.value.decode(), 'compute_units': cus.value, 'global_mem_bytes': mem.value}
 
+    def network_info(self):
+        """How the network was lowered: names the kernel instantiations a run launches (bsx_network_info)."""
+        nw, k, lm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._lib.bsx_network_info(self._h, C.byref(nw), C.byref(k), C.byref(lm)))
+        return {'state_words32': nw.value, 'mux_slots': k.value, 'lut_mode': lm.value}
+
     def synchronize(self):
         self._check(self._lib.bsx_synchronize(self._h))
 
@@ -183,6 +189,17 @@ class Engine:
                                        C.byref(st))
         self._check(rc)
         return AttractResult(table[:n_out.value].copy(), none.value, pp, st.as_dict())
+
+    def attract2(self, first, count, max_t=inf, max_len=inf, cap=65536):
+        """attract over [first, first + count) for flat problem indices / counts of up to 128 bits (bsx_run_attract2):
+        one call for the whole range however large -> AttractResult with a _lib.ATTR_REC2 table (wide sums)."""
+        table = getattr(self, '_attr_table2', None)
+        if table is None or len(table) < cap:
+            table = self._attr_table2 = np.zeros(cap, _lib.ATTR_REC2)
+        n_out, none, st = C.c_uint32(), _lib.U128(), _lib.Stats2()
+        self._check(self._lib.bsx_run_attract2(self._h, _lib.U128.of(first), _lib.U128.of(count), _cap(max_t), _cap(max_len),
+                                               ptr(table), cap, C.byref(n_out), C.byref(none), C.byref(st)))
+        return AttractResult(table[:n_out.value].copy(), int(none), None, st.as_dict())
 
     def target(self, first, count, max_t, mask_words, code_words, cap=None):
         cap = count if cap is None else cap

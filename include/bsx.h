@@ -40,12 +40,14 @@ typedef enum {
     BSX_ERR_INVALID = -1,        /* bad argument / inconsistent tables */
     BSX_ERR_NO_DEVICE = -2,      /* no gfx950 GPU, or HIP runtime failure at create */
     BSX_ERR_HIP = -3,            /* HIP call failed (text in bsx_last_error) */
-    BSX_ERR_UNSUPPORTED = -4,    /* network exceeds an engine limit (BSX_MAX_*) */
+    BSX_ERR_UNSUPPORTED = -4,    /* network / problem space exceeds an engine limit (BSX_MAX_*, variant >= 2^64) */
     BSX_ERR_TABLE_FULL = -5,     /* more distinct attractors / hits than the caller's capacity */
     BSX_ERR_STEP_LIMIT = -6,     /* a trajectory ran into the engine's internal step limit
                                     (only possible when max_t is BSX_T_INF or above that limit) */
     BSX_ERR_STATE = -7,          /* call order: network / problem space not set */
-    BSX_ERR_COMM = -8            /* RCCL: library not loadable, or an ncclXxx call failed */
+    BSX_ERR_COMM = -8,           /* RCCL: library not loadable, or an ncclXxx call failed */
+    BSX_ERR_RANGE_TOO_LARGE = -9 /* the call is valid but its result does not fit THIS entry point's record (a 64-bit
+                                    count / sum of a bsx_attr_rec overflowed): use bsx_run_attract2, or a smaller range */
 } bsx_status;
 
 /* Variation ranges = boolsi.constants.NodeStateRange (constants.py:23-30), digit -> state as in
@@ -118,6 +120,11 @@ const char* bsx_status_string(int status);
 int  bsx_device_info(bsx_handle h, char* name, uint32_t name_cap, uint32_t* compute_units,
                      uint64_t* global_mem_bytes);
 
+/* How the current network was lowered (valid after bsx_set_network): 32-bit words per state, gathered predecessor
+ * slots of the mux tree, and where the gather table lives (0 HBM / L2, 1 LDS per state byte, 2 LDS per 4 state bits).
+ * Together they name the kernel instantiations a run launches, e.g. k_attract_pool<words, slots, lut_mode, cube>. */
+int  bsx_network_info(bsx_handle h, uint32_t* state_words32, uint32_t* mux_slots, uint32_t* lut_mode);
+
 /* Network = (predecessor_node_lists, truth_tables) of the task tuple (batching.py:313-316).
  * pred_idx: predecessors of node i are pred_idx[pred_offsets[i] .. pred_offsets[i+1]) ascending
  * (input.py:796).  tt_words: table of node i starts at word tt_word_offsets[i] and has 2^k bits;
@@ -138,13 +145,51 @@ int  bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_words,
 /* attract (attract.py:262-302 semantics for every problem of [first, first + count)):
  * aggregated table (unordered) into table[0..*n_out), problems without attractor counted in
  * *n_no_attractor.  per_problem (count entries) may be NULL.
- * count <= 2^48 per call (a record's 64-bit sum of trajectory lengths must hold count x length; BSX_ERR_INVALID
- * beyond), <= 2^32 with per_problem.  Large aligned ranges are not enumerated problem by problem: the engine
- * steps classes of problems that provably share their trajectory from some update on (DESIGN.md "Cube collapse"). */
+ * A record's 64-bit count / sum_l and 128-bit sum_l2 must hold the result: BSX_ERR_RANGE_TOO_LARGE otherwise
+ * (bsx_run_attract2 has wide records); count <= 2^32 with per_problem.  Large aligned ranges are not enumerated
+ * problem by problem: the engine steps classes of problems that provably share their trajectory from some update
+ * on (DESIGN.md "Cube collapse"). */
 int  bsx_run_attract(bsx_handle h, const bsx_index* first, uint64_t count,
                      uint64_t max_t, uint64_t max_len,
                      bsx_attr_rec* table, uint32_t cap, uint32_t* n_out,
                      uint64_t* n_no_attractor, bsx_problem_rec* per_problem, bsx_stats* stats);
+
+/* ---- attract over ranges of any size ("bsx_u128 first, count: N = 2^a * 3^b can exceed 2^64") ----------
+ * The reference's N is a Python int (input.py:899-928) and ONE attract_master run covers it (attract.py:67-230);
+ * bsx_run_attract2 is that call.  first / count are the flat problem index I of batching.py:212-229 and a number of
+ * consecutive indices, 128 bits each; every sum of the record is wide enough for count = 2^128 problems of
+ * trajectory_l < 2^64 each.  Words are little-endian (word 0 least significant). */
+typedef struct { uint64_t lo, hi; } bsx_u128;
+
+typedef struct {
+    uint64_t key[BSX_MAX_WORDS];   /* min state code over the cycle (attract.py:296) */
+    uint64_t length;               /* attractor length */
+    bsx_u128 count;                /* frequency */
+    uint64_t sum_l[3];             /* 192-bit sum of trajectory_l */
+    uint64_t sum_l2[4];            /* 256-bit sum of trajectory_l^2 */
+} bsx_attr_rec2;
+
+typedef struct {
+    bsx_u128 problems;             /* as bsx_stats, wide */
+    bsx_u128 state_steps;
+    uint64_t executed_steps;
+    double   kernel_ms;            /* device time of all kernels of the call (HIP events on the engine's stream) */
+    double   total_ms;
+    double   dominant_ms;          /* ... of the dominant launches alone: the top level of every cube cascade */
+    uint64_t dominant_executed_steps;  /* network updates those launches executed (the roofline's numerator) */
+    uint32_t dominant_launches;
+    uint32_t kernel_launches;
+    uint32_t host_syncs;           /* times the host waited for the device inside the call */
+    uint32_t pad;
+} bsx_stats2;
+
+/* Same semantics and table contents as bsx_run_attract (which stays, for ranges whose sums fit 64 bits).
+ * A flat 128-bit index reaches every problem of spaces up to 2^128 problems; larger ones (more than 128 'any'
+ * nodes) are reached through bsx_index with bsx_run_attract.  BSX_ERR_INVALID if first + count leaves the space. */
+int  bsx_run_attract2(bsx_handle h, bsx_u128 first, bsx_u128 count,
+                      uint64_t max_t, uint64_t max_len,
+                      bsx_attr_rec2* table, uint32_t cap, uint32_t* n_out,
+                      bsx_u128* n_no_attractor, bsx_stats2* stats);
 
 /* attract through the functional graph (no reference analogue: the reference re-simulates every trajectory,
  * mpi.py:521-538): for spaces whose n <= 32 nodes are all 'any' (no variations, no perturbations) the network

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, 'include', 'bsx.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(bsx_[a-z_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(bsx_[a-z0-9_]+)\s*\(', text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -33,6 +33,8 @@ def test_struct_layouts_match_header():
     assert _lib.ATTR_REC.itemsize == 72
     assert _lib.PROBLEM_REC.itemsize == 56
     assert _lib.HIT.itemsize == 16
+    assert C.sizeof(_lib.U128) == 16 and C.sizeof(_lib.Stats2) == 88
+    assert _lib.ATTR_REC2.itemsize == 32 + 8 + 16 + 24 + 32
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
