@@ -49,6 +49,15 @@ constexpr uint32_t kPoolGroup = 64;             // problems loaded together = la
 
 constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
 
+// Rare blocks of the kernel's loop (listing a class, a member that is a cycle state itself, the next chunk of work) read
+// their parameters through this pointer instead of through `P`: it is the kernel-argument segment itself (P is the
+// kernel's only argument, at offset 0), made opaque, so the loads and the address arithmetic stay inside the rare block.
+// Through `P` the compiler hoists them in front of the loop, where they hold scalar registers for the whole launch --
+// 36 of them were spilled to VGPR lanes and scratch (profiles/r03_kernel_resources.csv, round 2's build).
+#define BSX_RARE_PARAMS(name)                                                                                          \
+    const AttractParams* name = reinterpret_cast<const AttractParams*>(__builtin_amdgcn_kernarg_segment_ptr());         \
+    asm volatile("" : "+s"(name))
+
 // OR the digits of `d` into `s` along the deposit plan (init_problem_simple without the origin).  With a
 // wave-uniform `d` this is scalar work.
 template <int NW>
@@ -344,10 +353,12 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     // one problem (sign = +1) or one problem less (-1) on the cycle state with tag word `tagw` at time mu: the same
     // bookkeeping as account() in absolute numbers, straight into the global correction sums (a handful per pass)
     auto account_fix = [&](uint32_t tagw, uint32_t mu, uint32_t lam, long long sign) {
+        BSX_RARE_PARAMS(Pr);
+        asm volatile("" : "+v"(mu));                        // (opaque: nothing derived from the literal is kept across the loop)
         const uint32_t tg = tagw & kTagMask, traj = tp + mu;
         const bool found = mu <= cap_rel && lam <= cap_rel - mu;
-        const bool keep = found && (uint64_t)lam <= P.max_len;
-        Counters* c = P.ctr;
+        const bool keep = found && (uint64_t)lam <= Pr->max_len;
+        Counters* c = Pr->ctr;
         if (found) atomicAdd(&c->fix_ref, (unsigned long long)(sign * (long long)(traj + lam)));
         else atomicAdd(&c->fix_capfail, (unsigned long long)sign);
         if (!keep) { atomicAdd(&c->fix_none, (unsigned long long)sign); return; }
@@ -416,7 +427,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         } else {
             // ---- fresh stage: the next 64 consecutive problems (chunks start on multiples of 64)
             if (q.next == q.end) {
-                const uint64_t b = first_dyn + grab_chunk(&P.ctr->cursor, chunk, (int)lane);
+                BSX_RARE_PARAMS(Pr);
+                const uint64_t b = first_dyn + grab_chunk(&Pr->ctr->cursor, chunk, (int)lane);
                 if (b >= n_items) { q.more = false; continue; }
                 q.next = b; q.end = (b + chunk < n_items) ? b + chunk : n_items;
             }
@@ -428,7 +440,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 fresh_pos = q.next;
                 fresh_state(fresh_pos, live, A);
             } else {
-                init_problem_simple<NW>(P.sp, q.next + lane, A);
+                // (lane made opaque: otherwise first_digits + lane is kept across the loop as a 64-bit per-lane value -- and spilled)
+                uint32_t lane_here = lane;
+                asm volatile("" : "+v"(lane_here));
+                init_problem_simple<NW>(P.sp, q.next + lane_here, A);
             }
             if (counting) {                                 // (mlo, mhi) = 64-bit member count
                 const unsigned long long members = 1ull << (cube ? P.cube_shift : 0u);
@@ -451,7 +466,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     if (et0) {
                         const uint32_t lam0 = NW <= 2 ? hit_len : lamtab[(et0 & kTagMask) - 1];
                         bool kept;
-                        account(et0, ((unsigned long long)mhi << 32) | mlo, 1u, lam0, kept);
+                        uint32_t one = 1u;
+                        unsigned long long m0 = ((unsigned long long)mhi << 32) | mlo;
+                        asm volatile("" : "+v"(one), "+v"(m0));
+                        account(et0, m0, one, lam0, kept);
                         account_fix(et0, 0u, lam0, 1ll);
                         account_fix(et0, 1u, lam0, -1ll);
                         live = false;
@@ -513,13 +531,14 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 const bool near = live && res != 0;
                 const uint64_t nb = __ballot(near);
                 if (nb) {
+                    BSX_RARE_PARAMS(Pr);
                     uint32_t S0[NW];
                     fresh_state(fresh_pos, near, S0);
                     uint32_t at0 = 0;
                     if (lane == 0) at0 = atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&lc[2], (uint32_t)__popcll(nb));    // the workgroup's own segment
                     const uint32_t at = __builtin_amdgcn_readfirstlane(at0) + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
-                    if (near && at < P.near_cap) {
-                        uint32_t* seg = P.near + ((uint64_t)blockIdx.x * P.near_cap + at) * NW;
+                    if (near && at < Pr->near_cap) {
+                        uint32_t* seg = Pr->near + ((uint64_t)blockIdx.x * Pr->near_cap + at) * NW;
 #pragma unroll
                         for (int w = 0; w < NW; ++w) seg[w] = S0[w];
                     }
@@ -571,20 +590,24 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         }
         // ---- classes past the FAST length go back as (group base, member mask)
         if (live && res == 0 && t >= fast_steps) {
-            if (counting && !cube) atomicOr(&P.ctr->straggler_overflow, 2u);    // members unknown: the host repeats the tile
-            atomicAdd(&P.ctr->n_stragglers, (unsigned long long)m);
-            const unsigned long long at = atomicAdd(&P.ctr->straggler_classes, 1ull);
+            BSX_RARE_PARAMS(Pr);
+            Counters* const c = Pr->ctr;
+            uint32_t* const list = Pr->stragglers;
+            const uint64_t list_cap = Pr->stragglers_cap;
+            if (counting && !cube) atomicOr(&c->straggler_overflow, 2u);    // members unknown: the host repeats the tile
+            atomicAdd(&c->n_stragglers, (unsigned long long)m);
+            const unsigned long long at = atomicAdd(&c->straggler_classes, 1ull);
             if (cube) {
                 // (state, t, member count): the host runs the detector from the state; an attractor it did not
                 // know yet means the pass is repeated, otherwise the class simply ran past the time cap
                 constexpr uint32_t kRec = NW + 3;
-                if (kRec * (at + 1) <= P.stragglers_cap) {
+                if (kRec * (at + 1) <= list_cap) {
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) P.stragglers[kRec * at + w] = A[w];
-                    P.stragglers[kRec * at + NW] = (uint32_t)t; P.stragglers[kRec * at + NW + 1] = mlo; P.stragglers[kRec * at + NW + 2] = mhi;
-                } else atomicOr(&P.ctr->straggler_overflow, 1u);
-            } else if (3 * at + 2 < P.stragglers_cap) { P.stragglers[3 * at] = base; P.stragglers[3 * at + 1] = mlo; P.stragglers[3 * at + 2] = mhi; }
-            else atomicOr(&P.ctr->straggler_overflow, 1u);
+                    for (int w = 0; w < NW; ++w) list[kRec * at + w] = A[w];
+                    list[kRec * at + NW] = (uint32_t)t; list[kRec * at + NW + 1] = mlo; list[kRec * at + NW + 2] = mhi;
+                } else atomicOr(&c->straggler_overflow, 1u);
+            } else if (3 * at + 2 < list_cap) { list[3 * at] = base; list[3 * at + 1] = mlo; list[3 * at + 2] = mhi; }
+            else atomicOr(&c->straggler_overflow, 1u);
         }
 
         // ---- merge lanes of one group that are in the same state (same group = same time)

@@ -255,17 +255,23 @@ def test_ranges_that_cross_the_64_digit_boundary_of_a_128_node_space(eng):
 
 
 def test_attract2_on_a_space_with_variations(eng):
-    """Perturbation variations: no cube path, the index carries into the variant number; one call = tiles inside."""
+    """Fixed-node and perturbation variations (not reachable through the YAML front end in attract mode, but allowed by
+    the C-ABI): no cube path, the flat index carries into the variant number; one call = detector tiles inside."""
     from oracle.cpu_oracle import Oracle
-    text = synth.network_yaml(14, 2, 141, perturbations={3: {'1?': '2'}, 7: {'0?': '1, 4'}}, fixed={5: '1'})
-    net, space = setup(eng, text, 64)
+    text = synth.network_yaml(14, 2, 141, initial={i: str(i & 1) for i in range(8, 14)}, fixed={5: 'any?', 2: '0?'},
+                              perturbations={3: {'1?': '2'}, 7: {'0?': '1, 4'}})
+    cfg = parse_input_text(text, 64, Mode.SIMULATE)             # parsed in a mode that allows variations
+    net, space = compile_problem(cfg)
+    eng.set_problem(net, space)
     total = space.n_problems
-    got = eng.attract2(0, total, 64)
-    _, table, none, steps = Oracle(net, space).attract(0, total, 64, per_problem=False, n_threads=CORES)
-    assert rows(got.table) == rows(table) and got.n_no_attractor == none and got.stats['state_steps'] == steps
-    mid = eng.attract2(total // 3, total // 2, 64)
-    _, table, none, steps = Oracle(net, space).attract(total // 3, total // 2, 64, per_problem=False, n_threads=CORES)
-    assert rows(mid.table) == rows(table) and mid.n_no_attractor == none
+    assert total == (1 << 8) * 3 * 2 * 2 * 2 * 2
+    orc = Oracle(net, space)
+    for first, count in ((0, total), (total // 3, total // 2), (total - 777, 777)):
+        got = eng.attract2(first, count, 64)
+        _, table, none, steps = orc.attract(first, count, 64, per_problem=False, n_threads=CORES)
+        assert rows(got.table) == rows(table) and got.n_no_attractor == none and got.stats['state_steps'] == steps
+    with pytest.raises(Exception):
+        eng.attract2(total - 5, 6, 64)
 
 
 def test_old_entry_point_reports_sums_that_do_not_fit(eng):
