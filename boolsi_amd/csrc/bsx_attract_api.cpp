@@ -23,7 +23,8 @@ constexpr uint32_t kFastStepsMax = 3072;
 constexpr uint64_t kProbeTile = 1ull << 22;     // lean tiles while the FAST length is being calibrated
 constexpr uint64_t kGeneralTile = 1ull << 32;   // problems per launch of the general kernel (32-bit offsets)
 constexpr uint64_t kUnresCap = 1ull << 18;      // cascade: unresolved classes a level may list
-constexpr uint64_t kNearBytes = 1ull << 30;     // cascade: list of the classes a level hands to the level below (segments + packed copy)
+constexpr uint64_t kNearBytes = 1ull << 32;     // cascade: list of the classes a level hands to the level below (segments, and again
+                                                // packed: a 2^63 block of the north star lists 7.5e7 classes of 12 bytes at its top)
 
 using MergedTable = std::unordered_map<Key8, WideRec, Key8Hash>;
 
@@ -552,11 +553,11 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
         const size_t shmem = h->shmem + (size_t)slots * h->cache_stride + 32 + pool_extra_bytes(h->net.nw);
         const Launch full = plan_persistent(h, ~0ull >> 8, shmem);         // the persistent grid (lower levels: size unknown here)
         const uint64_t seg_cap = std::getenv("BSX_CUBE_NEAR_CAP") ? (uint64_t)std::max(1, std::atoi(std::getenv("BSX_CUBE_NEAR_CAP")))     // (tests: force the shallower restart)
-                                                                    : std::max<uint64_t>(1, kNearBytes / (4 * nw) / full.grid.x);
+                                                                    : std::max<uint64_t>(1, kNearBytes / (4 * (nw + 1)) / full.grid.x);
         if (n_levels > 1) {
-            HIPCHK(h, h->d_near_seg.reserve((size_t)full.grid.x * seg_cap * nw));
+            HIPCHK(h, h->d_near_seg.reserve((size_t)full.grid.x * seg_cap * (nw + 1)));      // (state + the tag of its cycle)
             HIPCHK(h, h->d_near_counts.reserve(full.grid.x));
-            HIPCHK(h, h->d_near_list.reserve((size_t)full.grid.x * seg_cap * nw));
+            HIPCHK(h, h->d_near_list.reserve((size_t)full.grid.x * seg_cap * (nw + 1)));
         }
         HIPCHK(h, h->d_unres.reserve((size_t)n_levels * kUnresCap * rec_words));
 
@@ -612,7 +613,7 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
             HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem, h->stream, Q));
             if (i == 0) HIPCHK(h, hipEventRecord(h->ev_top1, h->stream));
             if (l.depth > 1)
-                HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, seg_cap, nw, h->d_near_list.p, h->d_level + i + 1, h->stream));
+                HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, seg_cap, nw + 1, h->d_near_list.p, h->d_level + i + 1, h->stream));
         }
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
         const double pt1 = now_ms();

@@ -31,6 +31,14 @@ __device__ __forceinline__ uint32_t bfi(uint32_t sel, uint32_t a, uint32_t b) {
     return r;
 }
 
+// The kernel's (only, by-value) parameter struct as an opaque pointer into the kernel-argument segment (offset 0).
+// What is read through it is loaded where it is used: the compiler cannot hoist the loads, or anything computed from
+// them, in front of the surrounding loop -- which is what it does with accesses through the parameter itself, and what
+// fills the scalar registers of the hot loop with values only a rare or one-off block needs.
+#define BSX_KERNARG(Type, name)                                                                          \
+    const Type* name = (const Type*)__builtin_amdgcn_kernarg_segment_ptr();                              \
+    asm volatile("" : "+s"(name))
+
 template <int NW>
 __device__ __forceinline__ bool eq_words(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
     uint32_t d = 0;

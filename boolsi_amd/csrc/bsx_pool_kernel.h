@@ -50,13 +50,11 @@ constexpr uint32_t kPoolGroup = 64;             // problems loaded together = la
 constexpr int pool_min_waves(int nw) { return nw <= 2 ? 6 : 2; }
 
 // Rare blocks of the kernel's loop (listing a class, a member that is a cycle state itself, the next chunk of work) read
-// their parameters through this pointer instead of through `P`: it is the kernel-argument segment itself (P is the
-// kernel's only argument, at offset 0), made opaque, so the loads and the address arithmetic stay inside the rare block.
-// Through `P` the compiler hoists them in front of the loop, where they hold scalar registers for the whole launch --
-// 36 of them were spilled to VGPR lanes and scratch (profiles/r03_kernel_resources.csv, round 2's build).
-#define BSX_RARE_PARAMS(name)                                                                                          \
-    const AttractParams* name = reinterpret_cast<const AttractParams*>(__builtin_amdgcn_kernarg_segment_ptr());         \
-    asm volatile("" : "+s"(name))
+// their parameters through the opaque kernel-argument pointer (bsx_kernels_common.h: BSX_KERNARG), so the loads and the
+// address arithmetic stay inside the rare block.  Through `P` the compiler hoists them in front of the loop, where they hold
+// scalar registers for the whole launch -- 36 of them were spilled to VGPR lanes and scratch in round 2's build
+// (profiles/r03_kernel_resources.csv).
+#define BSX_RARE_PARAMS(name) BSX_KERNARG(AttractParams, name)
 
 // OR the digits of `d` into `s` along the deposit plan (init_problem_simple without the origin).  With a
 // wave-uniform `d` this is scalar work.
@@ -180,6 +178,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     }
     // (a deep pass hands every class with members that close to a cycle to the level below instead)
     const uint32_t depth = (cube && P.cube_depth > 1u) ? P.cube_depth : 1u;   // uniform: updates of a fresh class before its first lookup
+    const bool from_entries = cube && P.entries != nullptr;                   // uniform: a lower level of a cascade
     // cube pass: cached cycle states inside the block get a second mirror entry, their class representative.
     // All threads look through the mirror; the few states found are inserted by thread 0.
     if constexpr (cube) {
@@ -262,6 +261,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #endif
 
     // cube pass: the representative state of class `pos + lane`
+    uint32_t ptag = 0;                      // entry-based pass: tag of the cycle the parent class's common state lies on
     auto fresh_state = [&](uint64_t pos, bool lv, uint32_t (&S0)[NW]) {
         // (a cube's plan has one run per enumerated digit, so run r is class-index bit r; pos is a multiple of 64)
         if ((pos >> 12) != u_hi_tag) {                      // uniform, rare
@@ -275,9 +275,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         for (int w = 0; w < NW; ++w) S0[w] = u_hi[w] | midtab[mid + w] | lane_part[w];
         if (P.entries) {                                    // uniform: a listed class of the level above, plus this level's digits
             const uint64_t e = (pos + lane) >> P.entry_shift;
-            if (lv) {
+            if (lv) {                                       // entry = the listed class's state + the tag of its cycle
 #pragma unroll
-                for (int w = 0; w < NW; ++w) S0[w] |= P.entries[e * NW + w];
+                for (int w = 0; w < NW; ++w) S0[w] |= P.entries[e * (NW + 1) + w];
+                ptag = P.entries[e * (NW + 1) + NW];
             }
         }
     };
@@ -538,12 +539,34 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     if (lane == 0) at0 = atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&lc[2], (uint32_t)__popcll(nb));    // the workgroup's own segment
                     const uint32_t at = __builtin_amdgcn_readfirstlane(at0) + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
                     if (near && at < Pr->near_cap) {
-                        uint32_t* seg = Pr->near + ((uint64_t)blockIdx.x * Pr->near_cap + at) * NW;
+                        uint32_t* seg = Pr->near + ((uint64_t)blockIdx.x * Pr->near_cap + at) * (NW + 1);
 #pragma unroll
                         for (int w = 0; w < NW; ++w) seg[w] = S0[w];
+                        seg[NW] = res & kTagMask;
                     }
                 }
                 if (near) { live = false; res = 0; }
+            }
+            if (from_entries) {
+                // A class of an entry-based pass is settled by its first lookup.  Its parent was listed because the
+                // parent's common state F^(depth+1)(x) is a cycle state; so either F^depth(x), just looked up, is one as
+                // well (the class is listed in turn, or -- depth 1 -- resolved below), or every member enters that very
+                // cycle with the next update: mu = depth + 1, nothing left to step.  Fresh classes all carry one unit, so
+                // the lanes of a tag are counted with a ballot and booked by one of them.
+                bool miss = live && res == 0;
+                uint64_t mb = __ballot(miss);
+                while (mb) {
+                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)ptag, __builtin_ctzll(mb));
+                    const bool same = miss && ptag == tg;
+                    const uint64_t sb = __ballot(same);
+                    if (lane == (uint32_t)__builtin_ctzll(sb)) {
+                        bool kept;
+                        account(tg, (cnt_t)((((unsigned long long)mhi << 32) | mlo) * (unsigned long long)__popcll(sb)), (uint32_t)t + 1u, lamtab[tg - 1], kept);
+                    }
+                    miss = miss && !same;
+                    mb &= ~sb;
+                }
+                if (res == 0) live = false;
             }
         }
 

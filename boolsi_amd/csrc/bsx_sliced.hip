@@ -157,9 +157,9 @@ __device__ __forceinline__ uint32_t bfi_s(uint32_t sel, uint32_t a, uint32_t b_u
     return r;
 }
 
-// One step for the rows of a wave.  DIGEST: the state being read, s(t - 1), is folded into the row's digest
-// accumulators first (X always, Y when `ymask` is all ones) -- the rows in LDS are final, perturbation
-// overrides included, which the values a wave has just computed are not.
+// One step for the rows of a wave.  DIGEST: the values just computed -- s(t) of the wave's rows -- are folded into the
+// rows' digest accumulators as they are written (X always, Y when `ymask` is all ones); the rare perturbation override
+// of a row corrects the fold where it overwrites the row (k_simulate_sliced64).
 template <int K, uint32_t RD, uint32_t WR, bool DIGEST>
 __device__ __forceinline__ void s64_step(const uint32_t (&addr)[kS64RowsPerWave][K],
                                          const uint32_t (&leaf_v)[kS64RowsPerWave][1 << (K - 1)],
@@ -168,23 +168,21 @@ __device__ __forceinline__ void s64_step(const uint32_t (&addr)[kS64RowsPerWave]
                                          uint32_t ymask) {
     typedef const bsx_u32x2 __attribute__((address_space(3))) lds_rd;
     typedef bsx_u32x2 __attribute__((address_space(3))) lds_wr;
+    // rows in flight between the reads and the writes: two (their LDS round trips overlap); the digest build, whose
+    // accumulators take 32 registers, one -- with two it spilled them
+    constexpr int B = DIGEST ? 1 : 2;
 #pragma unroll
-    for (int r0 = 0; r0 < kS64RowsPerWave; r0 += 2) {
+    for (int r0 = 0; r0 < kS64RowsPerWave; r0 += B) {
         if ((uint32_t)r0 >= rpw) break;                 // uniform
-        bsx_u32x2 g[2][K], own[2];
+        bsx_u32x2 g[B][K];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < B; ++u) {
 #pragma unroll
             for (int j = 0; j < K; ++j) g[u][j] = *reinterpret_cast<lds_rd*>(addr[r0 + u][j] + RD);
-            if constexpr (DIGEST) own[u] = *reinterpret_cast<lds_rd*>(out_addr + (uint32_t)(r0 + u) * kS64RowBytes + RD);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < B; ++u) {
             const int r = r0 + u;
-            if constexpr (DIGEST) {
-                acc_x[r].x ^= own[u].x; acc_x[r].y ^= own[u].y;
-                acc_y[r].x ^= own[u].x & ymask; acc_y[r].y ^= own[u].y & ymask;
-            }
             uint32_t x[1 << (K - 1)], y[1 << (K - 1)];
 #pragma unroll
             for (int i = 0; i < (1 << (K - 1)); ++i) {
@@ -200,6 +198,10 @@ __device__ __forceinline__ void s64_step(const uint32_t (&addr)[kS64RowsPerWave]
                 }
             bsx_u32x2 o;
             o.x = x[0]; o.y = y[0];
+            if constexpr (DIGEST) {
+                acc_x[r].x ^= o.x; acc_x[r].y ^= o.y;
+                acc_y[r].x ^= o.x & ymask; acc_y[r].y ^= o.y & ymask;
+            }
             if ((uint32_t)r < rpw) *reinterpret_cast<lds_wr*>(out_addr + (uint32_t)r * kS64RowBytes + WR) = o;     // uniform
         }
     }
@@ -209,6 +211,7 @@ template <int NW, int K, bool DIGEST>
 __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const SlicedParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     typedef uint32_t __attribute__((address_space(3))) lds_u32;
+    typedef bsx_u32x2 __attribute__((address_space(3))) lds_v2;
     // absolute LDS addressing (as net_step): the dynamic block must start at LDS address 0
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)smem != 0u) __builtin_trap();
     // (readfirstlane tells the compiler the wave index is uniform)
@@ -217,32 +220,20 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
     const uint32_t rpw = rows / kS64Waves;
     const uint32_t scratch = rows * kS64RowBytes;           // byte address of the transposition scratch
 
-    // ---- per-wave constants: leaf 2i+1 of a row in a VGPR, leaf 2i in an SGPR
-    uint32_t addr[kS64RowsPerWave][K], leaf_v[kS64RowsPerWave][1 << (K - 1)], leaf_s[kS64RowsPerWave][1 << (K - 1)];
-#pragma unroll
-    for (int r = 0; r < kS64RowsPerWave; ++r) {
-        const uint32_t row = wave * rpw + (uint32_t)r;
-        const bool live = (uint32_t)r < rpw;
-        const uint32_t* d = P.desc + (size_t)(live ? row : 0) * 8;
-#pragma unroll
-        for (int j = 0; j < K; ++j) addr[r][j] = d[j] * kS64RowBytes + lane * 8u;
-        const uint32_t tt = __builtin_amdgcn_readfirstlane(live ? d[6] : 0u);     // 2^K <= 8 table bits
-#pragma unroll
-        for (int i = 0; i < (1 << (K - 1)); ++i) {
-            leaf_v[r][i] = 0u - ((tt >> (2 * i + 1)) & 1u);
-            leaf_s[r][i] = 0u - ((tt >> (2 * i)) & 1u);
-        }
-    }
     const uint32_t out_addr = wave * rpw * kS64RowBytes + lane * 8u;
 
     // bits `bit` of the rows at byte offset `src` (+ node * row bytes) -> the NW state words of one trajectory
     auto gather = [&](uint32_t src, uint32_t bit, uint32_t (&s)[NW]) {
+        // (n made opaque here: otherwise the 128 `node < n` conditions are evaluated once in front of everything and
+        // held in scalar registers -- spilled to VGPR lanes -- through the step loop)
+        uint32_t n_here = n;
+        asm volatile("" : "+s"(n_here));
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             uint32_t word = 0;
             for (uint32_t b = 0; b < 32; ++b) {
                 const uint32_t node = (uint32_t)w * 32 + b;
-                if (node < n) word |= ((*reinterpret_cast<lds_u32*>(node * kS64RowBytes + src) >> bit) & 1u) << b;
+                if (node < n_here) word |= ((*reinterpret_cast<lds_u32*>(node * kS64RowBytes + src) >> bit) & 1u) << b;
             }
             s[w] = word;
         }
@@ -255,39 +246,78 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             __syncthreads();
-            for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x) {
-                Problem<NW> pr;
-                pr.s[w] = 0;
-                if (base + k < P.count) init_problem<NW>(P.sp, base + k, pr);
-                *reinterpret_cast<lds_u32*>(scratch + s64_skew(k) * 4u) = pr.s[w];
+            {
+                BSX_KERNARG(SlicedParams, Pk);      // (the enumeration's uniform conditions on the space stay in this block)
+                for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x) {
+                    Problem<NW> pr;
+                    pr.s[w] = 0;
+                    if (base + k < Pk->count) init_problem<NW>(Pk->sp, base + k, pr);
+                    *reinterpret_cast<lds_u32*>(scratch + s64_skew(k) * 4u) = pr.s[w];
+                }
             }
             __syncthreads();
+            // (lane made opaque: the 64 scratch addresses below are otherwise computed once in front of the group loop,
+            // kept for the whole launch and spilled to scratch)
+            uint32_t lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
             for (uint32_t b = wave * 2; b < wave * 2 + 2; ++b) {        // 16 waves x 2 = the word's 32 nodes
                 const uint32_t node = (uint32_t)w * 32 + b;
                 if (node >= rows) break;
                 uint32_t lo = 0, hi = 0;
                 if (node < n) {
                     for (uint32_t k = 0; k < 32; ++k) {
-                        lo |= ((*reinterpret_cast<lds_u32*>(scratch + s64_skew(lane * 64 + k) * 4u) >> b) & 1u) << k;
-                        hi |= ((*reinterpret_cast<lds_u32*>(scratch + s64_skew(lane * 64 + 32 + k) * 4u) >> b) & 1u) << k;
+                        lo |= ((*reinterpret_cast<lds_u32*>(scratch + s64_skew(lane_t * 64 + k) * 4u) >> b) & 1u) << k;
+                        hi |= ((*reinterpret_cast<lds_u32*>(scratch + s64_skew(lane_t * 64 + 32 + k) * 4u) >> b) & 1u) << k;
                     }
                 }
-                *reinterpret_cast<lds_u32*>(node * kS64RowBytes + lane * 8u) = lo;
-                *reinterpret_cast<lds_u32*>(node * kS64RowBytes + lane * 8u + 4u) = hi;
+                *reinterpret_cast<lds_u32*>(node * kS64RowBytes + lane_t * 8u) = lo;
+                *reinterpret_cast<lds_u32*>(node * kS64RowBytes + lane_t * 8u + 4u) = hi;
             }
         }
         __syncthreads();
 
+        // ---- the run's constants, loaded and expanded HERE, in front of every run, through an opaque pointer (so that the
+        // expansion cannot move in front of the group loop): per row K LDS addresses and 2^K leaf words -- leaf 2i+1 in a
+        // VGPR, leaf 2i in an SGPR (a VOP3 instruction reads one scalar register).  Held across the transpositions they
+        // were spilled to VGPR lanes and read back in every step (20 of the step's 80 instructions).
+        uint32_t addr[kS64RowsPerWave][K], leaf_v[kS64RowsPerWave][1 << (K - 1)], leaf_s[kS64RowsPerWave][1 << (K - 1)];
         bsx_u32x2 acc_x[kS64RowsPerWave], acc_y[kS64RowsPerWave];
+        {
+            const uint32_t* desc = P.desc;
+            asm volatile("" : "+s"(desc));
 #pragma unroll
-        for (int r = 0; r < kS64RowsPerWave; ++r) { acc_x[r].x = acc_x[r].y = 0; acc_y[r].x = acc_y[r].y = 0; }
+            for (int r = 0; r < kS64RowsPerWave; ++r) {
+                const bool live = (uint32_t)r < rpw;
+                const uint32_t* d = desc + (size_t)(live ? wave * rpw + (uint32_t)r : 0u) * 8;      // uniform: scalar loads
+#pragma unroll
+                for (int j = 0; j < K; ++j) addr[r][j] = d[j] * kS64RowBytes + lane * 8u;
+                const uint32_t tt = live ? d[6] : 0u;           // 2^K <= 8 table bits
+#pragma unroll
+                for (int i = 0; i < (1 << (K - 1)); ++i) {
+                    leaf_v[r][i] = 0u - ((tt >> (2 * i + 1)) & 1u);
+                    leaf_s[r][i] = __builtin_amdgcn_readfirstlane(0u - ((tt >> (2 * i)) & 1u));
+                }
+                acc_x[r].x = acc_x[r].y = 0; acc_y[r].x = acc_y[r].y = 0;
+                if constexpr (DIGEST) {                         // s(0) of the wave's rows (t = 0 belongs to Y iff digest_ybit(0))
+                    if (live) {
+                        const uint32_t ymask0 = 0u - digest_ybit(0u);
+                        const bsx_u32x2 v = *reinterpret_cast<lds_v2*>(out_addr + (uint32_t)r * kS64RowBytes);
+                        acc_x[r] = v;
+                        acc_y[r].x = v.x & ymask0; acc_y[r].y = v.y & ymask0;
+                    }
+                }
+            }
+        }
 
         // ---- T synchronous updates, buffer parity = (t - 1) & 1
+        // (32-bit clocks: max_t < 2^30, bsx_api.cpp)
         uint32_t sched_at = 0;
-        uint64_t next_t = P.n_sched ? (uint64_t)P.sched[0] : ~0ull;
-        for (uint64_t t = 1; t <= P.max_t; ++t) {
-            const bool odd = (t & 1ull) != 0;               // odd steps read buffer 0 and write buffer 1
-            const uint32_t ymask = DIGEST ? 0u - digest_ybit((uint32_t)(t - 1)) : 0u;     // the step folds s(t - 1)
+        const uint32_t t_end = (uint32_t)P.max_t, n_sched = P.n_sched;
+        const uint32_t* const sched = P.sched;
+        uint32_t next_t = n_sched ? sched[0] : 0xFFFFFFFFu;
+        for (uint32_t t = 1; t <= t_end; ++t) {
+            const bool odd = (t & 1u) != 0;                 // odd steps read buffer 0 and write buffer 1
+            const uint32_t ymask = DIGEST ? 0u - digest_ybit(t) : 0u;     // the step folds what it writes: s(t)
             if (odd) s64_step<K, 0u, 512u, DIGEST>(addr, leaf_v, leaf_s, out_addr, rpw, acc_x, acc_y, ymask);
             else s64_step<K, 512u, 0u, DIGEST>(addr, leaf_v, leaf_s, out_addr, rpw, acc_x, acc_y, ymask);
             // perturbation override at time t (model.py:68-71): whole rows of the buffer just written.
@@ -295,33 +325,36 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
             // has just stored, so the step's one barrier covers the override too.
             while (next_t <= t) {
                 if (next_t == t) {
-                    const uint32_t node = P.sched[3 * sched_at + 1];
-                    if (node - wave * rpw < rpw) {
-                        const uint32_t v = P.sched[3 * sched_at + 2] ? 0xFFFFFFFFu : 0u;
+                    const uint32_t node = sched[3 * sched_at + 1];
+                    const uint32_t mine = node - wave * rpw;            // uniform
+                    if (mine < rpw) {
+                        const uint32_t v = sched[3 * sched_at + 2] ? 0xFFFFFFFFu : 0u;
                         const uint32_t a = node * kS64RowBytes + (odd ? 512u : 0u) + lane * 8u;
+                        if constexpr (DIGEST) {
+                            // the fold took the computed value: replace it by the overriding one (the wave reads its own store)
+                            const bsx_u32x2 was = *reinterpret_cast<lds_v2*>(a);
+                            const uint32_t dx = was.x ^ v, dy = was.y ^ v;
+#pragma unroll
+                            for (int r = 0; r < kS64RowsPerWave; ++r) {
+                                const uint32_t sel = (uint32_t)r == mine ? 0xFFFFFFFFu : 0u;    // (static indices: the arrays stay in registers)
+                                acc_x[r].x ^= dx & sel; acc_x[r].y ^= dy & sel;
+                                acc_y[r].x ^= dx & sel & ymask; acc_y[r].y ^= dy & sel & ymask;
+                            }
+                        }
                         *reinterpret_cast<lds_u32*>(a) = v;
                         *reinterpret_cast<lds_u32*>(a + 4u) = v;
                     }
                 }
                 ++sched_at;
-                next_t = sched_at < P.n_sched ? (uint64_t)P.sched[3 * sched_at] : ~0ull;
+                next_t = sched_at < n_sched ? sched[3 * sched_at] : 0xFFFFFFFFu;
             }
             __syncthreads();
         }
         const uint32_t cur = (P.max_t & 1ull) ? 512u : 0u;      // buffer holding s(max_t)
 
-        // ---- digests: fold s(max_t), then X and Y rows go through the idle buffer, one after the other
+        // ---- digests: X and Y rows go through the idle buffer, one after the other
         uint64_t dg[kS64Group / (64 * kS64Waves)];
         if constexpr (DIGEST) {
-            typedef bsx_u32x2 __attribute__((address_space(3))) lds_v2;
-            const uint32_t ymask = 0u - digest_ybit((uint32_t)P.max_t);
-#pragma unroll
-            for (int r = 0; r < kS64RowsPerWave; ++r) {
-                if ((uint32_t)r >= rpw) break;
-                const bsx_u32x2 v = *reinterpret_cast<lds_v2*>(out_addr + (uint32_t)r * kS64RowBytes + cur);
-                acc_x[r].x ^= v.x; acc_x[r].y ^= v.y;
-                acc_y[r].x ^= v.x & ymask; acc_y[r].y ^= v.y & ymask;
-            }
             const uint32_t idle = cur ^ 512u;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -343,17 +376,22 @@ __global__ __launch_bounds__(64 * kS64Waves, 4) void k_simulate_sliced64(const S
 
         // ---- final states: thread handles trajectories tid, tid + 1024, ...
         uint32_t q = 0;
+        BSX_KERNARG(SlicedParams, Po);
+        const uint64_t count_o = Po->count;
+        const uint32_t w64_o = Po->w64;
+        uint64_t* const final_o = Po->final_states;
+        uint64_t* const digests_o = Po->digests;
         for (uint32_t k = threadIdx.x; k < kS64Group; k += blockDim.x, ++q) {
-            if (base + k >= P.count) break;
+            if (base + k >= count_o) break;
             uint32_t s[NW];
             gather((k >> 6) * 8u + ((k >> 5) & 1u) * 4u + cur, k & 31u, s);
-            if constexpr (DIGEST) P.digests[base + k] = digest_fold_words<NW>(dg[q], s, P.w64);
-            if (P.final_states) {
+            if constexpr (DIGEST) digests_o[base + k] = digest_fold_words<NW>(dg[q], s, w64_o);
+            if (final_o) {
 #pragma unroll
                 for (int w = 0; w < (NW + 1) / 2; ++w) {
                     uint64_t word = s[2 * w];
                     if (2 * w + 1 < NW) word |= (uint64_t)s[2 * w + 1] << 32;
-                    if ((uint32_t)w < P.w64) P.final_states[(base + k) * P.w64 + w] = word;
+                    if ((uint32_t)w < w64_o) final_o[(base + k) * w64_o + w] = word;
                 }
             }
         }

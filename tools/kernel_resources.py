@@ -21,7 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'boolsi_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-CXXFILT = '/opt/rocm/lib/llvm/bin/llvm-cxxfilt'
+CXXFILT = 'c++filt'
 
 # what the measured configurations launch (kernel name prefix -> who)
 LAUNCHED = {
