@@ -177,7 +177,8 @@ def main():
                 pmc = json.load(f)
             per_upd = pmc.get('per_executed_update') or {}
             if pmc.get('log2_batch') == args.log2_batch and per_upd:
-                units = {'valu': ('valu_insts', 1024), 'salu': ('salu_insts', 1024), 'lds': ('lds_busy_cycles', 256)}
+                # busy cycles of a unit, summed over its instances on the device (1024 SIMDs issue VALU / SALU, 256 CUs have an LDS)
+                units = {'valu': ('valu_busy_cycles', 1024), 'salu': ('salu_busy_cycles', 1024), 'lds': ('lds_busy_cycles', 256)}
                 clock_hz = pmc.get('shader_clock_hz', 2.4e9)
                 rates = {}
                 for unit, (key, lanes) in units.items():
@@ -188,13 +189,13 @@ def main():
                     unit = max(rates, key=lambda u: rates[u][0] / rates[u][1])
                     ach, peak = rates[unit]
                     roof = {'bound': {'valu': 'valu-issue', 'salu': 'salu-issue', 'lds': 'lds-pipeline'}[unit],
-                            'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'Ginst/s' if unit != 'lds' else 'Gcycle/s',
+                            'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'G busy unit-cycles/s',
                             'frac': ach / peak,
                             'traffic': pmc.get('hbm_bytes_per_launch'),
                             'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc passes of this command, not measured in this run)',
                             'all_units_frac': {u: r[0] / r[1] for u, r in rates.items()},
-                            'basis': 'instructions (LDS: busy cycles) per executed update from the PMC passes of this build x updates the '
-                                     'dominant launches executed in THIS run / their HIP-event duration; peak = units x shader clock',
+                            'basis': 'busy cycles of the unit per executed update (PMC passes of this build, ' + PMC_FILE + ') x updates the '
+                                     'dominant launches executed in THIS run / their HIP-event duration; peak = instances of the unit x shader clock',
                             'pmc_busy_fractions': pmc.get('issue_bound'), 'source': PMC_FILE}
         roof.update({'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3, 'launches_timed': dom_launches,
                      'executed_updates_per_launch': upd_per_launch,

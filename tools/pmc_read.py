@@ -1,10 +1,12 @@
 """Sum rocprofv3 --pmc counters per launch of one kernel from the CSVs under a directory and derive what bounds it.
-usage: python tools/pmc_read.py <dir with pmc_*/ sub-directories> [kernel-substring] [log2_batch]
-Writes one JSON object (profiles/<tag>_pmc.json is a copy of it; bench.py reads `hbm_bytes_per_launch` and
-`issue_bound` from there).  Counters are summed over the device; per launch = the LARGEST launches of the kernel
-(the bench's full tiles, not probe tiles).  gfx950 corrections (MI355X_MICROARCH.md): FETCH_SIZE counts half
-of wide reads, so it is doubled; FETCH_SIZE / WRITE_SIZE are in KiB units of the TCC; SQ_ACTIVE_INST_* /
-SQ_WAVE_CYCLES / SQ_WAIT_* are quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs."""
+usage: python tools/pmc_read.py <dir with pmc_*/ sub-directories and pmc_*.json bench lines> [kernel-substring] [log2_batch]
+Writes one JSON object (profiles/<tag>_pmc.json is a copy of it; bench.py reads `per_executed_update`, `shader_clock_hz`,
+`hbm_bytes_per_launch` and `issue_bound` from there).  Counters are summed over the device; per launch = the LARGEST
+launches of the kernel (the top level of every cascade, which is what bench.py times as the dominant kernel).
+gfx950 corrections (MI355X_MICROARCH.md): FETCH_SIZE counts half of wide reads, so it is doubled; FETCH_SIZE / WRITE_SIZE
+are in KiB units of the TCC; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* are quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs.
+The bench lines written by the same PMC passes give the updates those launches executed and their duration (serialised
+by the profiler, so only ratios to the counters of the same pass are used)."""
 import collections
 import csv
 import glob
@@ -24,10 +26,19 @@ for f in sorted(glob.glob(root + '/pmc_*/**/*counter_collection.csv', recursive=
 out = {'kernel': needle, 'log2_batch': log2_batch, 'counters_per_launch': {}, 'launches_seen': {}}
 for name, by in per.items():
     vals = sorted(by.values())
-    big = [v for v in vals if v >= 0.5 * vals[-1]] or vals         # full tiles only
+    big = [v for v in vals if v >= 0.5 * vals[-1]] or vals         # the dominant launches only
     out['counters_per_launch'][name] = sum(big) / len(big)
     out['launches_seen'][name] = len(big)
 c = out['counters_per_launch']
+lines = []
+for f in sorted(glob.glob(root + '/pmc_*.json')):
+    try:
+        lines.append(json.loads(open(f).read().strip().splitlines()[-1]))
+    except (ValueError, IndexError):
+        pass
+upd = [b['roofline']['executed_updates_per_launch'] for b in lines if 'roofline' in b]
+if upd:
+    out['executed_updates_per_launch'] = sum(upd) / len(upd)
 if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
     out['hbm_bytes_per_launch'] = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
     out['hbm_note'] = 'FETCH_SIZE x 2 (gfx950 counts half of wide reads) + WRITE_SIZE, KiB -> bytes, separate passes'
@@ -35,11 +46,15 @@ if 'GRBM_GUI_ACTIVE' in c:
     cycles = c['GRBM_GUI_ACTIVE'] / 8.0                          # shader cycles of the launch
     simds, cus = 1024, 256
     bound = {'launch_cycles': cycles}
+    busy = {}
     if 'SQ_ACTIVE_INST_VALU' in c:
-        bound['valu_busy_frac'] = 4 * c['SQ_ACTIVE_INST_VALU'] / (simds * cycles)
+        busy['valu_busy_cycles'] = 4 * c['SQ_ACTIVE_INST_VALU']
+        bound['valu_busy_frac'] = busy['valu_busy_cycles'] / (simds * cycles)
     if 'SQ_ACTIVE_INST_SCA' in c:
-        bound['salu_busy_frac'] = 4 * c['SQ_ACTIVE_INST_SCA'] / (simds * cycles)
+        busy['salu_busy_cycles'] = 4 * c['SQ_ACTIVE_INST_SCA']
+        bound['salu_busy_frac'] = busy['salu_busy_cycles'] / (simds * cycles)
     if 'SQ_LDS_IDX_ACTIVE' in c:
+        busy['lds_busy_cycles'] = c['SQ_LDS_IDX_ACTIVE']
         bound['lds_busy_frac'] = c['SQ_LDS_IDX_ACTIVE'] / (cus * cycles)
         if bound['lds_busy_frac'] > 1.0:
             bound['lds_note'] = ('above 1: the counters come from separate runs (clock and tile mix differ by a few percent) '
@@ -53,4 +68,14 @@ if 'GRBM_GUI_ACTIVE' in c:
             bound[k.lower() + '_per_launch'] = c[k]
     bound['reading'] = 'fractions of the launch during which the unit is busy, device average; the largest one is the bound'
     out['issue_bound'] = bound
+    if upd:
+        u = out['executed_updates_per_launch']
+        out['per_executed_update'] = {k: v / u for k, v in busy.items()}
+        for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS'):
+            if k in c:
+                out['per_executed_update'][k.lower()] = c[k] / u
+    ms = [b['roofline']['avg_launch_ms'] for b in lines if 'roofline' in b]
+    if ms:
+        out['shader_clock_hz'] = cycles / (sum(ms) / len(ms) * 1e-3)
+        out['clock_note'] = 'GRBM_GUI_ACTIVE / 8 XCDs / the launch duration of the same profiled runs'
 print(json.dumps(out, indent=1))
