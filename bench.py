@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--log2-batch', type=int, default=56, help='log2 of problems per GPU per step (<= 63)')
     ap.add_argument('--allow-socket-merge', action='store_true', help='N > 1: if RCCL cannot be set up, merge over the TCP control plane instead of failing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-table', metavar='PATH', help='rank 0 writes the merged attractor table of the timed steps there (JSON; tests)')
     ap.add_argument('--cpu-log2-sample', type=int, default=25, help='log2 of the problems the CPU baseline runs (2^25: ~12 s on the box)')
     args = ap.parse_args()
 
@@ -248,6 +249,9 @@ def main():
                                    'sample': 'first 2^{} problems of the same index range, CPU oracle '
                                              '(C, OpenMP; executes every update of the reference loop), {:.1f} s'.format(
                                                  args.cpu_log2_sample, dt)}
+        if args.dump_table:
+            with open(args.dump_table, 'w') as f:
+                json.dump({'{:x}'.format(k): [str(v) for v in e] for k, e in sorted(merged.items())}, f)
         print(json.dumps(out))
     comm.barrier()
     comm.shutdown()

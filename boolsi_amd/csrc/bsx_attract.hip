@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock, attract_min_waves(NW)) void k_attract(const
                 const uint64_t avail = q.end - q.next;
                 const uint64_t idle = __ballot(phase == PH_IDLE);
                 if (avail && idle) {
-                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    const uint32_t rank = rank_below(idle);
                     if (phase == PH_IDLE && rank < avail) {
                         my_p = q.next + rank;
                         if (P.offsets) my_p = P.offsets[my_p];

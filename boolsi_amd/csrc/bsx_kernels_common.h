@@ -39,6 +39,12 @@ __device__ __forceinline__ uint32_t bfi(uint32_t sel, uint32_t a, uint32_t b) {
     const Type* name = (const Type*)__builtin_amdgcn_kernarg_segment_ptr();                              \
     asm volatile("" : "+s"(name))
 
+// Number of set bits of `mask` below this lane's position (a lane's rank among the flagged lanes): v_mbcnt_lo/hi, no
+// per-lane (1 << lane) - 1 constant that would have to live in two VGPRs across the loop.
+__device__ __forceinline__ uint32_t rank_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 template <int NW>
 __device__ __forceinline__ bool eq_words(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
     uint32_t d = 0;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock, lean_min_waves(NW)) void k_attract_lean(con
                 const uint64_t avail = q.end - q.next;
                 const uint64_t idle = __ballot(res == kResIdle);
                 if (avail && idle) {
-                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    const uint32_t rank = rank_below(idle);
                     // with merging whole groups of kMergeGroup consecutive problems are loaded together (chunks
                     // start on group boundaries), so that their members share a clock and a member mask
                     uint64_t take = (uint64_t)__popcll(idle);

@@ -87,6 +87,7 @@ hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hip
 // bytes of LDS behind the cache mirror: per-attractor tables + per-wave pool, accumulators and id slots
 size_t pool_extra_bytes(uint32_t nw) {
     const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 8 + 8 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16 +
+                          32 +                      // + the workgroup's no-attractor / cap-failure / reference-step / executed sums
                           (size_t)64 * nw * 4;      // + the cube pass's mid-bit deposit table
     const size_t per_wave = ((size_t)kPoolCap * pool_rec_words(nw) + 128 + kPoolSlots / 4) * 4;
     return tables + (size_t)kPoolWaves * per_wave;

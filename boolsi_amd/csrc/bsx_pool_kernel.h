@@ -128,7 +128,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     uint32_t* keytab = lamtab + kAccs;
     constexpr uint32_t kWaveWords = kPoolCap * pool_rec_words(NW) + 128 + kPoolSlots / 4;
     static_assert(kAccs % 2 == 0 && kWaveWords % 2 == 0, "64-bit LDS atomics need 8-byte aligned tables");
-    uint32_t* midtab = keytab + ((kAccs * NW + 1u) & ~1u);      // cube pass: deposits of class-index bits 6..11, [64][NW]
+    // what does not end on a kept attractor (no-attractor counts, reference steps of the reference's loop, cap failures):
+    // rare with production caps, so it is summed in the workgroup's LDS as it happens instead of in three 64-bit registers
+    // per lane that lived across the whole loop (and were spilled to scratch)
+    unsigned long long* wg_ctr = reinterpret_cast<unsigned long long*>(keytab + ((kAccs * NW + 1u) & ~1u));    // [0] none, [1] cap failures, [2] reference steps
+    uint32_t* midtab = reinterpret_cast<uint32_t*>(wg_ctr + 4);  // cube pass: deposits of class-index bits 6..11, [64][NW]
     uint32_t* wave_base = midtab + 64 * NW + wave * kWaveWords;
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     if (image) { for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = image[i]; }
     else { for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0; }
     for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl2h[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
+    if (threadIdx.x < 4) wg_ctr[threadIdx.x] = 0;
     dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
     __syncthreads();
     if (!image && threadIdx.x == 0) {
@@ -243,8 +248,6 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     // member counts: 64 bits in a cube pass (a class stands for up to 2^48 problems), 32 bits otherwise (a tile
     // has at most 2^28 problems) -- the plain build keeps its registers
     using cnt_t = std::conditional_t<CUBE, unsigned long long, uint32_t>;
-    unsigned long long extra_ref = 0;
-    cnt_t n_none = 0, n_capfail = 0;
     uint32_t nexec = 0;
     // work queue: every wave's first chunk is fixed (wave w of the grid takes chunk w), only the chunks after those
     // come from the shared cursor -- a small pass has no traffic on that one address at all
@@ -330,9 +333,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         const bool keep = found && (uint64_t)lam <= P.max_len;              // attract.py:294
         keep_out = keep;
         if (__builtin_expect(!keep, 0)) {
-            n_none += m;
-            n_capfail += found ? (cnt_t)0 : m;
-            extra_ref += found ? (unsigned long long)m * (traj + lam) : 0ull;   // model.py:201
+            atomicAdd(&wg_ctr[0], (unsigned long long)m);
+            if (found) atomicAdd(&wg_ctr[2], (unsigned long long)m * (traj + lam));      // model.py:201
+            else atomicAdd(&wg_ctr[1], (unsigned long long)m);
         } else {
             // Straight into the workgroup's accumulators: a wave resolves less than one class per
             // iteration on average (64 problems end as one or two classes), so the LDS atomics do not
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     fresh_state(fresh_pos, near, S0);
                     uint32_t at0 = 0;
                     if (lane == 0) at0 = atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&lc[2], (uint32_t)__popcll(nb));    // the workgroup's own segment
-                    const uint32_t at = __builtin_amdgcn_readfirstlane(at0) + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
+                    const uint32_t at = __builtin_amdgcn_readfirstlane(at0) + rank_below(nb);
                     if (near && at < Pr->near_cap) {
                         uint32_t* seg = Pr->near + ((uint64_t)blockIdx.x * Pr->near_cap + at) * (NW + 1);
 #pragma unroll
@@ -550,23 +553,29 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             if (from_entries) {
                 // A class of an entry-based pass is settled by its first lookup.  Its parent was listed because the
                 // parent's common state F^(depth+1)(x) is a cycle state; so either F^depth(x), just looked up, is one as
-                // well (the class is listed in turn, or -- depth 1 -- resolved below), or every member enters that very
-                // cycle with the next update: mu = depth + 1, nothing left to step.  Fresh classes all carry one unit, so
-                // the lanes of a tag are counted with a ballot and booked by one of them.
-                bool miss = live && res == 0;
-                uint64_t mb = __ballot(miss);
-                while (mb) {
-                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)ptag, __builtin_ctzll(mb));
-                    const bool same = miss && ptag == tg;
+                // well -- the class is listed in turn (above) or, at depth 1, resolved with mu = 1 -- or every member enters
+                // the parent's cycle with the next update: mu = depth + 1, nothing left to step.  Fresh classes all carry
+                // one unit and share t, so the lanes of an outcome (tag, mu) are counted with a ballot and booked by one of
+                // them -- and the iteration ends here: nothing of such a pass ever reaches the pool.
+                const bool hit = live && res != 0;                          // (depth 1 only: deeper hits were listed)
+                uint32_t otag = hit ? (res & kTagMask) : ptag;
+                bool todo = live;
+                uint64_t tb = __ballot(todo);
+                while (tb) {
+                    const int first = __builtin_ctzll(tb);
+                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)otag, first);
+                    const bool h0 = __builtin_amdgcn_readlane((int)(hit ? 1u : 0u), first) != 0;
+                    const bool same = todo && otag == tg && hit == h0;
                     const uint64_t sb = __ballot(same);
-                    if (lane == (uint32_t)__builtin_ctzll(sb)) {
+                    if (lane == (uint32_t)first) {
                         bool kept;
-                        account(tg, (cnt_t)((((unsigned long long)mhi << 32) | mlo) * (unsigned long long)__popcll(sb)), (uint32_t)t + 1u, lamtab[tg - 1], kept);
+                        account(tg, (cnt_t)((((unsigned long long)mhi << 32) | mlo) * (unsigned long long)__popcll(sb)),
+                                (uint32_t)t + (h0 ? 0u : 1u), lamtab[tg - 1], kept);
                     }
-                    miss = miss && !same;
-                    mb &= ~sb;
+                    todo = todo && !same;
+                    tb &= ~sb;
                 }
-                if (res == 0) live = false;
+                continue;
             }
         }
 
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         if (dbg_is_fresh) dbg_fresh_keep += __popcll(keepers); else dbg_pool_keep += __popcll(keepers);
 #endif
         if (cand) {
-            const uint32_t rank = __popcll(keepers & ((1ull << lane) - 1ull));
+            const uint32_t rank = rank_below(keepers);
             uint32_t tail = head + count;                   // uniform; head < cap, count <= cap
             tail -= tail >= kCap ? kCap : 0u;
             uint32_t ri = tail + rank;
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         if (nb) {
             unsigned long long at0 = 0;
             if (!cube && lane == 0) at0 = atomicAdd(&P.ctr->log_cursor, (unsigned long long)__popcll(nb));
-            const unsigned long long at = bcast64(at0, 0) + __popcll(nb & ((1ull << lane) - 1ull));
+            const unsigned long long at = bcast64(at0, 0) + rank_below(nb);
             if (cn) {
                 const unsigned long long sl = acc_sl[a];
                 if constexpr (cube) {
@@ -763,7 +772,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 } else {
                     atomicOr(&P.ctr->log_overflow, 1u);
                 }
-                extra_ref += sl + cn * lamtab[a];                                   // + lambda each (model.py:201)
+                atomicAdd(&wg_ctr[2], sl + cn * lamtab[a]);                         // + lambda each (model.py:201)
             }
         }
     }
@@ -781,17 +790,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     }
 #endif
     // counters: summed over the workgroup in LDS first (the accumulators are free now), one global atomic each
-    __syncthreads();
-    if (threadIdx.x < 3) acc_sl2[threadIdx.x] = 0;
-    __syncthreads();
     {
-        const unsigned long long w_ref = wave_sum(extra_ref + (P.cap_rel_inf ? 0ull : (unsigned long long)n_capfail * P.max_t));
-        const unsigned long long w_exec = wave_sum((unsigned long long)nexec), w_none = wave_sum((unsigned long long)n_none);
-        if (lane == 0) {
-            if (w_ref) atomicAdd(&acc_sl2[0], w_ref);
-            if (w_exec) atomicAdd(&acc_sl2[1], w_exec);
-            if (w_none) atomicAdd(&acc_sl2[2], w_none);
-        }
+        const unsigned long long w_exec = wave_sum((unsigned long long)nexec);
+        if (lane == 0 && w_exec) atomicAdd(&wg_ctr[3], w_exec);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -803,9 +804,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 if (listed > P.near_cap) atomicOr(&P.ctr->near_overflow, 1u);
             }
         }
-        if (acc_sl2[0]) atomicAdd(&P.ctr->steps_ref, acc_sl2[0]);
-        if (acc_sl2[1]) atomicAdd(&P.ctr->steps_exec, acc_sl2[1]);
-        if (acc_sl2[2]) atomicAdd(&P.ctr->n_none, acc_sl2[2]);
+        const unsigned long long ref = wg_ctr[2] + (P.cap_rel_inf ? 0ull : wg_ctr[1] * P.max_t);
+        if (ref) atomicAdd(&P.ctr->steps_ref, ref);
+        if (wg_ctr[3]) atomicAdd(&P.ctr->steps_exec, wg_ctr[3]);
+        if (wg_ctr[0]) atomicAdd(&P.ctr->n_none, wg_ctr[0]);
     }
 }
 

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
             const uint64_t avail = q.end - q.next;
             const uint64_t idle = __ballot(phase == PH_IDLE);
             if (avail && idle) {
-                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t rank = rank_below(idle);
                 if (phase == PH_IDLE && rank < avail) {
                     my_p = q.next + rank;
                     if (simple_space) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const uint32_t* t_hit, ui
         const uint64_t m = __ballot(hit);
         if (lane == 0) wave_tot[wave] = __popcll(m);
         __syncthreads();
-        uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+        uint32_t before = rank_below(m);
         for (int w = 0; w < wave; ++w) before += wave_tot[w];
         const uint32_t all = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         if (hit && out + before < hits_cap) { hits[out + before].offset = p; hits[out + before].t = t; }

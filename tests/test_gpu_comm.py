@@ -81,3 +81,51 @@ def test_comm_layer_merges_through_rccl(eng, tmp_path, monkeypatch):
     as_rows = lambda res: [(a.key, a.length, a.frequency, a.sum_l, a.sum_l2) for a in res[0]]
     assert as_rows(with_rccl) == as_rows(alone) and with_rccl[1:3] == alone[1:3]
     comm.shutdown()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_as_child_processes_equal_one_rank(tmp_path):
+    """bench.py --gpus 2 as the driver launches it -- one fresh process per rank, rendezvous from RANK / WORLD_SIZE /
+    MASTER_* -- here with both ranks on GPU 0 and the socket data plane (RCCL refuses two ranks per device): the merged
+    table of the timed steps must equal the table one rank computes over the same blocks, and the line must say which
+    data plane carried the merge.  Without BSX_DIST_BACKEND=socket or --allow-socket-merge the run must fail instead of
+    downgrading by itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(world, steps, warmup, extra_env, out_name, expect_ok=True):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), BSX_BENCH_DEVICE='0', BSX_RDZV_TIMEOUT='120', **extra_env)
+            if world == 1:
+                for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+                    env.pop(k)
+            cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', str(warmup),
+                   '--log2-batch', '48', '--no-cpu-baseline', '--dump-table', str(tmp_path / out_name)]
+            procs.append(subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=600) for p in procs]
+        codes = [p.returncode for p in procs]
+        if not expect_ok:
+            return codes, outs
+        assert codes == [0] * world, outs
+        line = json.loads(outs[0][0].strip().splitlines()[-1])
+        return line, json.load(open(tmp_path / out_name))
+
+    two, table2 = run(2, 3, 1, {'BSX_DIST_BACKEND': 'socket'}, 'two.json')          # timed blocks 2 .. 7
+    one, table1 = run(1, 6, 2, {}, 'one.json')                                       # the same blocks on one rank
+    assert two['n_gpus'] == 2 and 'socket' in two['config']['merge'] and one['n_gpus'] == 1
+    assert table2 == table1 and len(table1) == 2
+    assert two['roofline']['kernel'] == 'k_attract_pool<2,2,1,true>'
+    assert abs(two['attractors_per_s'] / (6 * 2 ** 48 / (two['ms_per_step'] * 3e-3)) - 1) < 1e-6
+    # RCCL cannot serve two ranks on one device: no flag, no downgrade -- every rank exits non-zero
+    codes, outs = run(2, 1, 1, {}, 'never.json', expect_ok=False)
+    assert all(c != 0 for c in codes), outs
