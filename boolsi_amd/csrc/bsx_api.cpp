@@ -199,12 +199,19 @@ extern "C" int bsx_set_network(bsx_handle h, uint32_t n_nodes, const uint32_t* p
         const uint64_t tt = tt_words[tt_word_offsets[i]];
         for (uint32_t idx = 0; idx < (1u << k_mux); ++idx)      // replicate over the unused high slots
             if ((tt >> (idx & ((1u << k) - 1))) & 1ull) masks[(size_t)idx * nw + (i >> 5)] |= 1u << (i & 31);
+        // entry = [slot j][word w]; 6-word entries in two planes: words 0..3 of every entry, then words 4..5 (net_step)
+        const bool planar = k_mux * nw == 6 && lut_mode != 2;
+        const size_t plane_b = (size_t)n_chunks * chunk_entries * 4;
         for (uint32_t j = 0; j < k; ++j) {
             const uint32_t p = pred_idx[pred_offsets[i] + j];
             const uint32_t chunk = p / chunk_bits, bit = p % chunk_bits;
             for (uint32_t v = 0; v < chunk_entries; ++v)
-                if ((v >> bit) & 1u)
-                    lut[(((size_t)chunk * chunk_entries + v) * k_mux + j) * nw + (i >> 5)] |= 1u << (i & 31);
+                if ((v >> bit) & 1u) {
+                    const size_t ent = (size_t)chunk * chunk_entries + v;
+                    const uint32_t word = j * nw + (i >> 5);
+                    const size_t at = !planar ? ent * k_mux * nw + word : (word < 4 ? ent * 4 + word : plane_b + ent * 2 + (word - 4));
+                    lut[at] |= 1u << (i & 31);
+                }
         }
     }
     std::vector<uint32_t> wdesc, wpreds, wtt;

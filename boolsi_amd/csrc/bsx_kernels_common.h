@@ -218,6 +218,25 @@ __device__ __forceinline__ void net_step(const NetView<NW, K, LM>& nv, const uin
                 if constexpr (LM == kLutLdsNibble) {
                     const uint32_t off = ((s[ch >> 3] >> ((ch & 7) * 4)) & 15u) * (uint32_t)(kEntry * 4);
                     load_entry_lds<kEntry>(NetView<NW, K, LM>::kLutLdsAddr + (uint32_t)(ch << 4) * kEntry * 4u + off, e[b]);
+                } else if constexpr (kEntry == 6) {
+                    // 24-byte entries (n <= 64 with K = 3, n <= 32 with K = 6) are stored as two planes -- the first four
+                    // words of every entry (16 bytes, one b128 read), then the last two (one b64 read): three b64 reads at
+                    // a 24-byte stride kept the LDS pipeline 95 % busy with two thirds of it bank conflicts (k_attract<2,3,1>
+                    // on a chaotic network, profiles/r03_pmc_chaotic.json)
+                    const uint32_t off = byte_times(s[ch >> 2], 16u, ch & 3);
+                    constexpr uint32_t kPlaneB = (uint32_t)kLookups * 256u * 16u;       // bytes of the first plane
+                    uint32_t lo4[4], hi2[2];
+                    if constexpr (LDS) {
+                        load_entry_lds<4>(NetView<NW, K, LM>::kLutLdsAddr + (uint32_t)(ch << 8) * 16u + off, lo4);
+                        load_entry_lds<2>(NetView<NW, K, LM>::kLutLdsAddr + kPlaneB + (uint32_t)(ch << 8) * 8u + (off >> 1), hi2);
+                    } else {
+                        const char* base = reinterpret_cast<const char*>(nv.lut);
+                        load_entry<4>(reinterpret_cast<const uint32_t*>(base + (uint32_t)(ch << 8) * 16u + off), lo4);
+                        load_entry<2>(reinterpret_cast<const uint32_t*>(base + kPlaneB + (uint32_t)(ch << 8) * 8u + (off >> 1)), hi2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e[b][i] = lo4[i];
+                    e[b][4] = hi2[0]; e[b][5] = hi2[1];
                 } else {
                     // byte offset of the entry within its chunk's table: (byte ch of the state) * entry size,
                     // one SDWA multiply instead of extract + scale

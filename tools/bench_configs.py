@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """
 Secondary measurements: the BASELINE.json configs other than the headline one, on one GPU.
-    python tools/bench_configs.py [--quick] [--no-cpu]
+    python tools/bench_configs.py [--quick] [--no-cpu] [--only config4]       (--only: one config, e.g. under rocprofv3 --pmc)
 One JSON line per config and path, each with
   roofline      SURVEY 8(d) basis (0.25 B per executed node update / kernel time / 8 TB/s; for the functional-graph
                 mode the bytes its passes stream through HBM), <= 1 by construction;
@@ -30,18 +30,43 @@ HBM_PEAK_GBS = 8000.0
 CORES = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
 
 
-def roofline(bytes_moved, kernel_ms, bound='hbm', note=None):
+def pmc_of(key):
+    """What the separate rocprofv3 --pmc passes of this config measured (tools/profile_configs.sh -> profiles/r03_pmc_<key>.json)."""
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_{}.json'.format(key))
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def roofline(bytes_moved, kernel_ms, bound='hbm-normalised', note=None, pmc_key=None):
     achieved = bytes_moved / (kernel_ms * 1e-3) / 1e9
     r = {'bound': bound, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
          'traffic': None}
     if note:
         r['basis'] = note
+    pmc = pmc_of(pmc_key) if pmc_key else None
+    if pmc:
+        # the unit the counters show busiest names the bound; the normalised HBM figure stays next to it
+        ib = pmc.get('issue_bound') or {}
+        fr = {k[:-10]: v for k, v in ib.items() if k.endswith('_busy_frac')}
+        r['traffic'] = pmc.get('hbm_bytes_per_launch')
+        r['traffic_source'] = 'profiles/r03_pmc_{}.json (separate --pmc passes, kernel {})'.format(pmc_key, pmc.get('kernel'))
+        if fr:
+            unit = max(fr, key=fr.get)
+            r['hbm_normalised'] = {'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS}
+            r.update({'bound': {'valu': 'valu-issue', 'salu': 'salu-issue', 'lds': 'lds-pipeline'}[unit], 'frac': min(fr[unit], 1.0),
+                      'achieved': min(fr[unit], 1.0), 'peak': 1.0, 'unit': 'busy fraction of the launch (PMC)', 'busy_fractions': fr})
     return r
 
 
 def main():
     quick = '--quick' in sys.argv
     with_cpu = '--no-cpu' not in sys.argv
+    only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
+
+    def want(key):
+        return only is None or only == key
     from oracle.cpu_oracle import Oracle            # CPU baseline leg only
     eng = Engine(0)
 
@@ -57,7 +82,9 @@ def main():
         return {'value': steps * net.n_nodes / dt, 'unit': 'node-state-updates/s', 'attractors_per_s': sample / dt, 'cores': CORES,
                 'kind': 'port', 'sample': 'first {} problems, CPU oracle (C, OpenMP), {:.1f} s'.format(sample, dt)}
 
-    def attract(name, text, first, count, max_t, cpu_sample, paths=('default',)):
+    def attract(name, text, first, count, max_t, cpu_sample, paths=('default',), key=None):
+        if not want(key or name.split()[0]):
+            return
         cfg = parse_input_text(text, max_t, Mode.ATTRACT)
         net, space = compile_problem(cfg)
         eng.set_problem(net, space)
@@ -91,7 +118,8 @@ def main():
                 merged, none, st = run_attract_range(eng, first, count, max_t)
                 dt = time.perf_counter() - t0
                 roof = roofline(st['executed_steps'] * net.n_nodes * 0.25, st['kernel_ms'],
-                                note='0.25 B per executed node update (SURVEY 8d); states stay in registers/LDS')
+                                note='0.25 B per executed node update (SURVEY 8d); states stay in registers/LDS',
+                                pmc_key=(key or name.split()[0]) if path == 'default' else None)
             os.environ.pop('BSX_CUBES', None)
             emit({'config': name, 'path': path, 'mode': 'attract', 'n': net.n_nodes, 'problems': count, 'attractors': len(merged),
                   'no_attractor': none, 'wall_s': dt, 'kernel_ms': st['kernel_ms'], 'kernel_launches': st['kernel_launches'],
@@ -108,8 +136,25 @@ def main():
     attract('config3 synthetic n=32 K=2, all 2^32 problems', synth.config3_yaml(), 0, 1 << (28 if quick else 32), 4096, 1 << 25,
             paths=('default', 'plain enumeration (BSX_CUBES=0)') + (() if quick else ('functional graph',)))
     attract('north-star n=64 K=2, 2^40 problems', synth.north_star_yaml(), 0x0123456789ABCDEF & ~((1 << 40) - 1),
-            1 << (34 if quick else 40), 4096, 1 << 25)
+            1 << (34 if quick else 40), 4096, 1 << 25, key='northstar40')
+    # a network outside the ordered regime: K = 3, p = 1/2 is chaotic -- nothing collapses, cycles are longer than the cache
+    # takes, every trajectory runs the detector (k_attract<2,3,1>); most of them run into the -t cap
+    # (seed 12 of tools/depth_survey.py's K = 3 rows: 5.7 s per 2^26 problems in round 2)
+    attract('chaotic n=64 K=3 seed 12, 2^{} problems, -t 4096'.format(18 if quick else 22), synth.network_yaml(64, 3, 12), 0,
+            1 << (18 if quick else 22), 4096, 1 << 14, key='chaotic')
+    if not (want('config4') or want('config5')):
+        eng.close()
+        return
 
+    if want('config4'):
+        config4(eng, emit, quick, with_cpu)
+    if want('config5'):
+        config5(eng, emit, quick, with_cpu)
+    eng.close()
+
+
+def config4(eng, emit, quick, with_cpu):
+    from oracle.cpu_oracle import Oracle
     # config 4: target, n = 64, 8 knock-out variants x 2^28 initial states; summary sink (count + histogram + first 1000 hits)
     cfg = parse_input_text(synth.config4_yaml(), 1024, Mode.TARGET)
     net, space = compile_problem(cfg)
@@ -132,9 +177,13 @@ def main():
           'problems': count, 'hits': int(n_hits), 'listed': len(first_hits), 'mean_first_hit_t': float((hist * np.arange(len(hist))).sum() / max(n_hits, 1)),
           'wall_s': dt, 'kernel_ms': st['kernel_ms'], 'kernel_launches': st['kernel_launches'],
           'executed_node_updates_per_s': st['executed_steps'] * 64 / dt, 'problems_per_s': count / dt,
-          'roofline': roofline(st['executed_steps'] * 64 * 0.25, st['kernel_ms'], note='0.25 B per executed node update (SURVEY 8d)'),
+          'roofline': roofline(st['executed_steps'] * 64 * 0.25, st['kernel_ms'], note='0.25 B per executed node update (SURVEY 8d)',
+                               pmc_key='config4'),
           'cpu_baseline': cpu})
 
+
+def config5(eng, emit, quick, with_cpu):
+    from oracle.cpu_oracle import Oracle
     # config 5: simulate -t 10000, n = 128, K = 3, perturbation schedule; final states + fold digests
     cfg = parse_input_text(synth.config5_yaml(), 10000, Mode.SIMULATE)
     net, space = compile_problem(cfg)
@@ -154,7 +203,9 @@ def main():
             # 32 trajectories, 2^K - 1 = 7 muxes per node update -> 7/32 lane-instructions per node update; the chip
             # issues 1024 SIMDs x 64 lanes x clock / 4 cycles per wave-instruction.
             peak = 1024 * 64 * 2.1e9 / 4 / (7 / 32)
-            return {'bound': 'valu', 'achieved': rate, 'peak': peak, 'unit': 'node-updates/s', 'frac': rate / peak, 'traffic': None,
+            pmc = pmc_of('config5') or {}
+            return {'bound': 'valu-issue', 'achieved': rate, 'peak': peak, 'unit': 'node-updates/s', 'frac': rate / peak,
+                    'traffic': pmc.get('hbm_bytes_per_launch'), 'pmc_busy_fractions': pmc.get('issue_bound'),
                     'basis': 'VALU issue bound of the mux tree (7 v_bfi per 32 node updates at K = 3, 2.1 GHz); the state matrix never '
                              'leaves LDS (T = 10000), HBM traffic is the initial / final states only',
                     'survey_8d_streaming_equivalent_GBps': rate * 0.25 / 1e9}
@@ -191,7 +242,6 @@ def main():
         emit({'config': 'config5 FULL: 2^26 problems x 10000 steps, digests', 'mode': 'simulate', 'n': 128, 'problems': 1 << 26, 'wall_s': dt,
               'kernel_ms': kms, 'xor_of_all_digests': int(acc), 'node_updates_per_s': (1 << 26) * 10000 * 128 / dt,
               'roofline': sim_roofline('bit-sliced', {'executed_steps': (1 << 26) * 10000, 'kernel_ms': kms})})
-    eng.close()
 
 
 if __name__ == '__main__':
