@@ -103,6 +103,11 @@ extern "C" int bsx_destroy(bsx_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < 8; ++i) {
+        if (h->aux_done[i]) (void)hipEventDestroy(h->aux_done[i]);
+        if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
+    }
+    if (h->h_ctr_multi) (void)hipHostFree(h->h_ctr_multi);
     if (h->ev_top0) (void)hipEventDestroy(h->ev_top0);
     if (h->ev_top1) (void)hipEventDestroy(h->ev_top1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -398,6 +403,20 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
 }
 
 
+constexpr size_t kAuxStreams = 8, kMultiCtr = 64;
+
+// Auxiliary streams of the handle (created on first use): independent launches of one call run side by side on them.
+static int ensure_aux(bsx_handle h) {
+    if (h->aux[0]) return BSX_OK;
+    for (size_t i = 0; i < kAuxStreams; ++i) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->aux_done[i], hipEventDisableTiming));
+    }
+    HIPCHK(h, h->d_ctr_multi.alloc(kMultiCtr));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_ctr_multi, sizeof(Counters) * kMultiCtr, hipHostMallocDefault));
+    return BSX_OK;
+}
+
 // One k_target launch over [first, first + count): optional dense t_hit, optional histogram.
 static int launch_target_pass(bsx_handle h, const bsx_index* first, uint64_t skip, uint64_t count, uint64_t max_t,
                               const uint64_t* mask_words, const uint64_t* code_words, uint32_t* d_thit,
@@ -553,7 +572,7 @@ extern "C" int bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint
     };
     // the listed hits first: dense pieces of the range
     while (done < count && listed < cap) {
-        const uint64_t piece = std::min<uint64_t>(count - done, std::max<uint64_t>(1ull << 22, 4 * (cap - listed)));
+        const uint64_t piece = std::min<uint64_t>(count - done, std::max<uint64_t>(1ull << kCubeMinBits, 4 * (cap - listed)));
         HIPCHK(h, d_thit.reserve(std::min<uint64_t>(piece, 1ull << 32)));
         const uint64_t n = std::min<uint64_t>(piece, d_thit.n);
         if (int rc = plain_pass(done, n, true)) return rc;
@@ -564,6 +583,43 @@ extern "C" int bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint
     const char* cubes_env = std::getenv("BSX_CUBES");
     const bool cubes_ok = !(cubes_env && cubes_env[0] == '0') && h->sp.n_any >= kCubeMinBits && h->sp.n_any <= 64 &&
                           (h->sp.identity_any || h->sp.n_runs) && !h->sp.n_pv && !h->sp.tp_origin && !h->variant_count_saturated;
+    // The cube passes of a call are independent of each other -- one per aligned block and fixed-node variant, each a
+    // short launch of one-class-per-lane searches that mostly waits (profiles/r03_pmc_config4.json: 90 % of the wave
+    // cycles) -- so they are enqueued side by side on the handle's auxiliary streams, every launch with its own counter
+    // block, and the host waits once for all of them (config 4: eight launches of 0.34 ms each back to back before).
+    struct PendingCube { TargetParams P; dim3 grid; size_t shmem; uint32_t a_bits; uint64_t variant; uint32_t rel; };
+    std::vector<PendingCube> pending;
+    auto flush_cubes = [&]() -> int {
+        if (pending.empty()) return BSX_OK;
+        const size_t n = pending.size();
+        if (int rc = ensure_aux(h)) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_ctr_multi.p, 0, n * sizeof(Counters), h->stream));
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        const size_t used = std::min<size_t>(n, kAuxStreams);
+        for (size_t i = 0; i < used; ++i) HIPCHK(h, hipStreamWaitEvent(h->aux[i], h->ev0, 0));
+        for (size_t i = 0; i < n; ++i) {
+            pending[i].P.ctr = h->d_ctr_multi.p + i;
+            HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, pending[i].grid, pending[i].shmem, h->aux[i % kAuxStreams], pending[i].P));
+        }
+        for (size_t i = 0; i < used; ++i) {
+            HIPCHK(h, hipEventRecord(h->aux_done[i], h->aux[i]));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->aux_done[i], 0));
+        }
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_ctr_multi, h->d_ctr_multi.p, n * sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        kernel_ms += ms;
+        for (size_t i = 0; i < n; ++i) {
+            const Counters& ctr = h->h_ctr_multi[i];
+            total += ctr.log_cursor; steps_ref += ctr.steps_ref; steps_exec += ctr.steps_exec;
+            ++launches; limit_hits += ctr.step_limit_hits;
+            if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] target cube 2^%u, variant %llu: %u relevant digits (%zu launches side by side, %.3f ms together)\n", pending[i].a_bits, (unsigned long long)pending[i].variant, pending[i].rel, n, ms);
+        }
+        pending.clear();
+        return BSX_OK;
+    };
     while (done < count) {
         if (!cubes_ok) {
             const uint64_t n = std::min<uint64_t>(count - done, 1ull << 32);
@@ -638,25 +694,20 @@ extern "C" int bsx_run_target_summary(bsx_handle h, const bsx_index* first, uint
                 P.hist_bins = hist_bins ? hist_bins : 1;
                 const size_t shmem = h->shmem + 16 + (size_t)P.hist_bins * 8;
                 const Launch L = plan_persistent(h, P.count, shmem);
-                P.chunk = L.chunk;
-                Counters ctr{};
-                float ms = 0.f;
-                HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
-                HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-                HIPCHK(h, launch_target((int)h->net.nw, (int)h->net.k_mux, h->lut_mode, L.grid, shmem, h->stream, P));
-                HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-                HIPCHK(h, hipMemcpyAsync(&ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(h, hipStreamSynchronize(h->stream));
-                HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-                total += ctr.log_cursor; steps_ref += ctr.steps_ref; steps_exec += ctr.steps_exec;
-                kernel_ms += ms; ++launches; limit_hits += ctr.step_limit_hits;
-                if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] target cube 2^%u, variant %llu: %zu relevant digits, %.3f ms\n", a_bits, (unsigned long long)variant, c.rel.size(), ms);
+                {   // even fixed shares, no cursor traffic (P.count <= 2^64 / ... classes of about equal cost)
+                    const uint64_t n_waves = (uint64_t)L.grid.x * kWavesPerBlock;
+                    if (P.count < (1ull << 28)) { P.chunk_first = ((P.count + n_waves - 1) / n_waves + 63) / 64 * 64; P.chunk = 0; }
+                    else { P.chunk_first = 0; P.chunk = L.chunk; }
+                }
+                pending.push_back(PendingCube{P, L.grid, shmem, a_bits, variant, (uint32_t)c.rel.size()});
+                if (pending.size() == kMultiCtr) if (int rc = flush_cubes()) return rc;
             } else if (int rc = plain_pass(done, block, false)) return rc;
             done += block;
             at += block;
         }
         if (seg_end > body_end) { if (int rc = plain_pass(done, (uint64_t)(seg_end - body_end), false)) return rc; done += (uint64_t)(seg_end - body_end); }
     }
+    if (int rc = flush_cubes()) return rc;
     if (hist_bins) HIPCHK(h, hipMemcpy(hist, d_hist.p, hist_bins * sizeof(uint64_t), hipMemcpyDeviceToHost));
     *n_hits = total;
     if (n_listed) *n_listed = listed;

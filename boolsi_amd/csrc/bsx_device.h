@@ -272,6 +272,7 @@ struct TargetParams {
     uint32_t cube_shift;
     uint32_t cube_t0_shift;
     uint32_t pad;
+    uint64_t chunk_first;       // work items every wave starts with (its fixed share; `chunk` at a time from the cursor after that)
     uint32_t rep_mask[kMaxW32];
     uint32_t rep_code[kMaxW32];
 };

@@ -116,6 +116,11 @@ struct bsx_engine {
     volatile uint32_t* h_flag = nullptr;    // (behind h_ctr in the same pinned allocation)
     uint32_t flag_seq = 0;
     hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;    // around the top-level (dominant) launch of a cascade
+    // independent launches of one call side by side (target's cube passes): auxiliary streams, one counter block per launch
+    hipStream_t aux[8] = {};
+    hipEvent_t aux_done[8] = {};
+    bsx::DevBuf<bsx::Counters> d_ctr_multi;
+    bsx::Counters* h_ctr_multi = nullptr;
 
     // functional-graph mode (bsx_fgraph.hip): N-sized arrays, kept between calls (grow-only)
     bsx::DevBuf<uint32_t> d_fg_a, d_fg_b, d_fg_c, d_fg_warm;

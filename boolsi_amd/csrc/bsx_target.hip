@@ -44,7 +44,16 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
     uint64_t members = 1;       // problems this lane's trajectory stands for (cube pass: 2^cube_shift minus the t = 0 hits)
     uint32_t limit_hits = 0;
     bool skip0 = false;         // cube pass: the t = 0 check was done per member when the class was set up
-    WaveQueue q{0, 0, true};
+    // work: every wave starts with a fixed share (chunk_first work items, 0 = none); what lies beyond the shares comes
+    // from the shared cursor, P.chunk at a time (0 = nothing lies beyond).  Same-address atomics complete at some 15 ns
+    // apiece, so the short cube passes, whose classes cost about the same everywhere, are split evenly and never touch it.
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t first_dyn = (uint64_t)gridDim.x * kWavesPerBlock * P.chunk_first;
+    WaveQueue q{0, 0, P.chunk != 0 && P.count > first_dyn};
+    if (P.chunk_first) {
+        const uint64_t b = ((uint64_t)blockIdx.x * kWavesPerBlock + wave) * P.chunk_first;
+        if (b < P.count) { q.next = b; q.end = (b + P.chunk_first < P.count) ? b + P.chunk_first : P.count; }
+    }
 
     for (;;) {
         const uint32_t n_run = __popcll(__ballot(phase >= PH_WARM));
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(kBlock, NW <= 2 ? 4 : 2) void k_target(const Target
         if (work_left && (64u - n_run >= kServiceLanes || n_run == 0)) {
             // ---- refill idle lanes with the next problems of the wave's chunk
             if (q.next == q.end) {
-                const uint64_t base = grab_chunk(&P.ctr->cursor, P.chunk, lane);
+                const uint64_t base = first_dyn + grab_chunk(&P.ctr->cursor, P.chunk, lane);
                 if (base >= P.count) q.more = false;
                 else { q.next = base; q.end = (base + P.chunk < P.count) ? base + P.chunk : P.count; }
             }
