@@ -121,7 +121,7 @@ def main():
     def checked(results):
         """every problem of every step accounted for (exact, wide); -> the step tables"""
         for r in results:
-            assert sum(record_ints(a)[2] for a in r.table) + r.n_no_attractor == batch
+            assert sum(c[0] | c[1] << 64 for c in r.table['count'].tolist()) + r.n_no_attractor == batch
         return [r.table for r in results]
 
     warm = []

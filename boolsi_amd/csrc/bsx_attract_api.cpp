@@ -523,6 +523,7 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
     };
 
     for (int attempt = 0; attempt < 32; ++attempt) {
+        const double pt_plan = now_ms();
         // every cached attractor must be in the mirror, or a class could sit on a cycle nobody recognises
         uint32_t slots = 0;
         h->cube_mirror = true;
@@ -626,7 +627,7 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
             HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         }
         HIPCHK(h, hipEventElapsedTime(&ms_top, h->ev_top0, h->ev_top1));
-        g_prof[1] += pt1 - pt0; g_prof[2] += pt2 - pt1; g_prof[3] += ms;
+        g_prof[0] += pt0 - pt_plan; g_prof[1] += pt1 - pt0; g_prof[2] += pt2 - pt1; g_prof[3] += ms;
         tot.kernel_ms += ms;
         tot.launches += 2 * n_levels - 1;
         tot.dominant_ms += ms_top;
