@@ -553,8 +553,11 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
         }
         const size_t shmem = h->shmem + (size_t)slots * h->cache_stride + 32 + pool_extra_bytes(h->net.nw);
         const Launch full = plan_persistent(h, ~0ull >> 8, shmem);         // the persistent grid (lower levels: size unknown here)
+        // classes a level may hand down: as many as the top level has (a level that lists more than that is not worth its
+        // launch: the block is redone shallower), at most what 4 GiB hold; split evenly over the workgroups' segments
+        const uint64_t list_cap = std::min<uint64_t>(kNearBytes / (4 * (nw + 1)), std::max<uint64_t>(1ull << 16, 1ull << lv[0].k_bits));
         const uint64_t seg_cap = std::getenv("BSX_CUBE_NEAR_CAP") ? (uint64_t)std::max(1, std::atoi(std::getenv("BSX_CUBE_NEAR_CAP")))     // (tests: force the shallower restart)
-                                                                    : std::max<uint64_t>(1, kNearBytes / (4 * (nw + 1)) / full.grid.x);
+                                                                    : std::max<uint64_t>(64, list_cap / full.grid.x);
         if (n_levels > 1) {
             HIPCHK(h, h->d_near_seg.reserve((size_t)full.grid.x * seg_cap * (nw + 1)));      // (state + the tag of its cycle)
             HIPCHK(h, h->d_near_counts.reserve(full.grid.x));
@@ -610,8 +613,11 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
                 Q.entries = h->d_near_list.p;               // (packed by the k_compact_near before this launch)
                 Q.level_in = h->d_level + i;
                 Q.chunk = 0; Q.chunk_first = 0;
+                // the lower-level build of the kernel: no pool, no rings (its LDS is the tables alone)
+                Q.lower_build = (Q.mirror_image && !(std::getenv("BSX_CUBE_LOWER") && std::getenv("BSX_CUBE_LOWER")[0] == '0')) ? 1u : 0u;
             }
-            HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem, h->stream, Q));
+            const size_t shmem_here = Q.lower_build ? h->shmem + (size_t)slots * h->cache_stride + 32 + pool_lower_extra_bytes(nw) : shmem;
+            HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem_here, h->stream, Q));
             if (i == 0) HIPCHK(h, hipEventRecord(h->ev_top1, h->stream));
             if (l.depth > 1)
                 HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, seg_cap, nw + 1, h->d_near_list.p, h->d_level + i + 1, h->stream));

@@ -11,6 +11,7 @@ constexpr int kPoolBlockThreads = 768;      // the pool kernel's workgroup (bsx_
 constexpr uint32_t kPoolCap = 112;          // ... classes per wave (ring buffer; > 64 + what a fresh stage leaves)
 constexpr uint32_t kPoolSlots = 128;        // ... merge slots per wave (one-byte lane ids; 256 slots: 2 % fewer updates, not worth 1.5 KiB of LDS)
 constexpr uint32_t pool_rec_words(uint32_t nw) { return nw + 4; }      // ... ring record: state, group base, members lo/hi, time
+constexpr uint32_t kLowerFoundWords = 256;  // ... lower-level build: room for the list of cycle states inside the block
 constexpr int kMaxW32 = 8;                  // 32-bit words per state (n <= 256)
 constexpr int kMaxMuxK = 6;                 // nodes with more predecessors take the "wide" path
 constexpr int kTableSlots = 64;             // per-wave attractor table: one slot per lane (registers)
@@ -228,6 +229,8 @@ struct AttractParams {
     // above has run, so its number of work items comes from the device: count = level_in->n_entries << entry_shift
     // (nothing to do when that is 0 or level_in->abort is set), and the split over the waves is derived from it there.
     const LevelDesc* level_in;
+    uint32_t lower_build;       // cube pass: launch the lower-level build of the kernel (entries != null, the mirror as an image)
+    uint32_t pad2;
 };
 
 // Cube collapse, ordering heuristic: how long does a flip of each relevant digit stay visible?  One thread per

@@ -27,6 +27,7 @@ hipError_t configure_attract_fast(int nw, int k, int lut_mode, size_t shmem, int
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P);
 hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int* blocks_per_cu);
 size_t pool_extra_bytes(uint32_t nw);
+size_t pool_lower_extra_bytes(uint32_t nw);
 hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
 hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw, uint32_t* out, LevelDesc* desc, hipStream_t stream);
 hipError_t launch_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq, hipStream_t stream);

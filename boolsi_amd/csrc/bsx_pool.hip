@@ -85,6 +85,10 @@ hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hip
 }
 
 // bytes of LDS behind the cache mirror: per-attractor tables + per-wave pool, accumulators and id slots
+size_t pool_lower_extra_bytes(uint32_t nw) {      // the lower-level build: the same tables, no rings
+    return (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 8 + 8 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16 + 32 +
+           (size_t)64 * nw * 4 + (size_t)kLowerFoundWords * 4 + (size_t)kPoolWaves * 2 * (kTagAcc + kLdsAcc) * 4;     // + per-wave outcome counts
+}
 size_t pool_extra_bytes(uint32_t nw) {
     const size_t tables = (size_t)(kTagAcc + kLdsAcc) * (8 + 8 + 8 + 8 + 4) + (((size_t)(kTagAcc + kLdsAcc) * nw + 1) & ~size_t(1)) * 4 + 16 +
                           32 +                      // + the workgroup's no-attractor / cap-failure / reference-step / executed sums

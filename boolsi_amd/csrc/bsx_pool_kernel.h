@@ -73,8 +73,12 @@ __device__ __forceinline__ void deposit_runs(const DevSpace& sp, uint64_t d, uin
 
 // CUBE = true: the cube-pass build of the kernel (P.merge == 3): member counts only, no member masks, no
 // per-problem records; kept apart so that neither build carries the other's registers.
-template <int NW, int K, int LM, bool CUBE>
+// LOWER = true (with CUBE): the build for the lower levels of a chained cascade -- entry-based passes, whose classes are all
+// settled by their first lookup (see the main loop), so it has no pool, no rings in LDS and two batches of 64 classes in
+// flight per iteration.
+template <int NW, int K, int LM, bool CUBE, bool LOWER = false>
 __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool(const AttractParams P) {
+    static_assert(CUBE || !LOWER, "the lower-level build is a cube build");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* smem_free;
 #ifdef BSX_DIAG
@@ -126,14 +130,16 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     unsigned long long* acc_cnt = acc_sl + kAccs;
     uint32_t* lamtab = reinterpret_cast<uint32_t*>(acc_cnt + kAccs);
     uint32_t* keytab = lamtab + kAccs;
-    constexpr uint32_t kWaveWords = kPoolCap * pool_rec_words(NW) + 128 + kPoolSlots / 4;
+    constexpr uint32_t kWaveWords = LOWER ? 0u : kPoolCap * pool_rec_words(NW) + 128 + kPoolSlots / 4;
+    constexpr uint32_t kFoundWords = LOWER ? kLowerFoundWords : 0u;     // (the other builds borrow wave 0's ring for that list)
+    constexpr uint32_t kLowerCntWords = LOWER ? 2u * kAccs : 0u;        // lower-level build, per wave: classes by outcome (tag, hit / miss)
     static_assert(kAccs % 2 == 0 && kWaveWords % 2 == 0, "64-bit LDS atomics need 8-byte aligned tables");
     // what does not end on a kept attractor (no-attractor counts, reference steps of the reference's loop, cap failures):
     // rare with production caps, so it is summed in the workgroup's LDS as it happens instead of in three 64-bit registers
     // per lane that lived across the whole loop (and were spilled to scratch)
     unsigned long long* wg_ctr = reinterpret_cast<unsigned long long*>(keytab + ((kAccs * NW + 1u) & ~1u));    // [0] none, [1] cap failures, [2] reference steps
     uint32_t* midtab = reinterpret_cast<uint32_t*>(wg_ctr + 4);  // cube pass: deposits of class-index bits 6..11, [64][NW]
-    uint32_t* wave_base = midtab + 64 * NW + wave * kWaveWords;
+    uint32_t* wave_base = midtab + 64 * NW + kFoundWords + wave * (kWaveWords + kLowerCntWords);
     typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
     typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
     lds_vu32* const pool = (lds_vu32*)(__attribute__((address_space(3))) uint32_t*)wave_base;
@@ -150,7 +156,8 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     else { for (uint32_t i = threadIdx.x; i < lc_words; i += blockDim.x) lc[i] = 0; }
     for (uint32_t i = threadIdx.x; i < kAccs; i += blockDim.x) { acc_sl2[i] = 0; acc_sl2h[i] = 0; acc_sl[i] = 0; acc_cnt[i] = 0; lamtab[i] = 0; }
     if (threadIdx.x < 4) wg_ctr[threadIdx.x] = 0;
-    dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0;
+    if constexpr (!LOWER) { dd_acc[2 * lane] = 0; dd_acc[2 * lane + 1] = 0; }
+    else { wave_base[lane] = 0; wave_base[64 + lane] = 0; }
     __syncthreads();
     if (!image && threadIdx.x == 0) {
         uint32_t seen = 0, n_states = 0, n_attr = 0;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         if (threadIdx.x == 0) { lc[1] = 0; lc[2] = 0; }     // lc[1]: cycle states inside the block, lc[2]: classes listed for the level below
         __syncthreads();
         if (depth == 1u && !has_warmup) {
-            constexpr uint32_t kFoundCap = kCap * R;          // slots of the states found go to wave 0's ring (not in use yet)
+            constexpr uint32_t kFoundCap = LOWER ? kLowerFoundWords : kCap * R;     // slots of the states found go to wave 0's ring (not in use yet)
             auto inside = [&](uint32_t sl) -> bool {
                 const uint32_t* e = cbase + sl * S;
                 const uint32_t tw = e[NW];
@@ -379,7 +386,131 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #ifdef BSX_DIAG
     const unsigned long long dbg_t1 = wall_clock64();
 #endif
-    for (;;) {
+    if constexpr (LOWER) {
+        // ---- lower level of a cascade: every class is settled by its first lookup (the reasoning is at `from_entries` in
+        // the general loop below), so an iteration is: two batches of 64 classes -- entry + this level's digits -> `depth`
+        // updates -> one lookup -> listed for the level below (depth > 1), or booked by outcome with a ballot.  The two
+        // batches are independent chains of LDS / HBM round trips that overlap; nothing lives across iterations.
+        // Outcomes are counted per wave in LDS -- slot 2 (tag - 1) for the classes that are resolved by the lookup itself
+        // (depth 1), + 1 for those that enter their parent's cycle with the next update -- and booked once, at the end:
+        // the bookkeeping of an outcome (a 128-bit product, the caps) is some fifty instructions, which per batch and
+        // outcome was half of what a batch of one-update classes executed.
+        uint32_t* const wave_cnt = wave_base;
+        constexpr int B = 2;
+        for (;;) {
+            if (q.next == q.end) {
+                if (!q.more) break;
+                BSX_RARE_PARAMS(Pr);
+                const uint64_t b = first_dyn + grab_chunk(&Pr->ctr->cursor, chunk, (int)lane);
+                if (b >= n_items) { q.more = false; continue; }
+                q.next = b; q.end = (b + chunk < n_items) ? b + chunk : n_items;
+            }
+            uint32_t S[B][NW], tagp[B], et[B];
+            bool lv[B];
+            uint64_t pos[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const uint64_t avail = q.end - q.next;
+                const uint32_t n = avail < 64u ? (uint32_t)avail : 64u;
+                lv[b] = lane < n;
+                pos[b] = q.next;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) S[b][w] = 0;
+                tagp[b] = 0;
+                if (n) { fresh_state(pos[b], lv[b], S[b]); tagp[b] = ptag; }
+                q.next += n;
+            }
+            if (t0_lookup) {                                // (depth 1: a member that is a cycle state itself, as below)
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    uint32_t h0;
+                    const uint32_t et0 = lv[b] ? probe(S[b], h0, true) : 0u;
+                    if (et0) {
+                        const uint32_t lam0 = lamtab[(et0 & kTagMask) - 1];
+                        bool kept;
+                        uint32_t one = 1u;
+                        unsigned long long m0 = 1ull << P.cube_shift;
+                        asm volatile("" : "+v"(one), "+v"(m0));
+                        account(et0, m0, one, lam0, kept);
+                        account_fix(et0, 0u, lam0, 1ll);
+                        account_fix(et0, 1u, lam0, -1ll);
+                        lv[b] = false;
+                    }
+                }
+            }
+            for (uint32_t i = 1; i < depth; ++i) {
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    if (lv[b]) {
+                        uint32_t nx[NW];
+                        net_step<NW, K>(nv, S[b], fm0, fv0, nx, has_fixed);
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) S[b][w] = nx[w];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                et[b] = 0;
+                if (lv[b]) {
+                    uint32_t nx[NW], hf;
+                    net_step<NW, K>(nv, S[b], fm0, fv0, nx, has_fixed);
+                    et[b] = probe(nx, hf);
+                    nexec += depth;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (depth > 1u) {
+                    // F^depth(x) on a cycle: the members' entry times differ -- list the class for the level below
+                    const bool near = lv[b] && et[b] != 0;
+                    const uint64_t nb = __ballot(near);
+                    if (nb) {
+                        BSX_RARE_PARAMS(Pr);
+                        uint32_t S0[NW];
+                        fresh_state(pos[b], near, S0);
+                        uint32_t at0 = 0;
+                        if (lane == 0) at0 = atomicAdd((uint32_t*)(__attribute__((address_space(3))) uint32_t*)&lc[2], (uint32_t)__popcll(nb));
+                        const uint32_t at = __builtin_amdgcn_readfirstlane(at0) + rank_below(nb);
+                        if (near && at < Pr->near_cap) {
+                            uint32_t* seg = Pr->near + ((uint64_t)blockIdx.x * Pr->near_cap + at) * (NW + 1);
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) seg[w] = S0[w];
+                            seg[NW] = et[b] & kTagMask;
+                        }
+                    }
+                    if (near) lv[b] = false;
+                }
+                const bool hit = lv[b] && et[b] != 0;                       // (depth 1 only)
+                const uint32_t otag = hit ? (et[b] & kTagMask) : tagp[b];
+                bool todo = lv[b];
+                uint64_t tb = __ballot(todo);
+                while (tb) {
+                    const int first = __builtin_ctzll(tb);
+                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane((int)otag, first);
+                    const bool h0 = __builtin_amdgcn_readlane((int)(hit ? 1u : 0u), first) != 0;
+                    const bool same = todo && otag == tg && hit == h0;
+                    const uint64_t sb = __ballot(same);
+                    if (lane == (uint32_t)first) atomicAdd(&wave_cnt[2u * (tg - 1u) + (h0 ? 0u : 1u)], (uint32_t)__popcll(sb));
+                    todo = todo && !same;
+                    tb &= ~sb;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t half = 0; half < 2; ++half) {         // lane l books slots l and 64 + l
+            const uint32_t idx = half * 64u + lane;
+            const uint32_t n_classes = *(volatile uint32_t*)&wave_cnt[idx];
+            if (n_classes) {
+                const uint32_t tg = idx / 2u + 1u;
+                bool kept;
+                account(tg, (cnt_t)(((unsigned long long)n_classes) << P.cube_shift), depth + (idx & 1u), lamtab[tg - 1], kept);
+            }
+        }
+    }
+    if constexpr (!LOWER) for (;;) {
         const bool input = q.more || q.next < q.end;
         if (!input && count == 0) break;
 #ifdef BSX_DIAG
@@ -856,9 +987,13 @@ static hipError_t launch_life_nk(int lut_mode, dim3, size_t shmem, hipStream_t s
 }
 
 template <int NW, int K>
-static const void* pool_kernel_for(int lut_mode, bool cube) {
+static const void* pool_kernel_for(int lut_mode, bool cube, bool lower = false) {
     const void* fn = nullptr;
-    if (cube) {
+    if (lower) {
+        if (lut_mode == kLutLdsByte) fn = (const void*)k_attract_pool<NW, K, kLutLdsByte, true, true>;
+        else if (lut_mode == kLutGlobal) fn = (const void*)k_attract_pool<NW, K, kLutGlobal, true, true>;
+        else if constexpr (NW >= 4) { if (lut_mode == kLutLdsNibble) fn = (const void*)k_attract_pool<NW, K, kLutLdsNibble, true, true>; }
+    } else if (cube) {
         if (lut_mode == kLutLdsByte) fn = (const void*)k_attract_pool<NW, K, kLutLdsByte, true>;
         else if (lut_mode == kLutGlobal) fn = (const void*)k_attract_pool<NW, K, kLutGlobal, true>;
         else if constexpr (NW >= 4) { if (lut_mode == kLutLdsNibble) fn = (const void*)k_attract_pool<NW, K, kLutLdsNibble, true>; }
@@ -871,15 +1006,15 @@ static const void* pool_kernel_for(int lut_mode, bool cube) {
 }
 template <int NW, int K>
 static hipError_t launch_pool_nk(int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
-    const void* fn = pool_kernel_for<NW, K>(lut_mode, P.merge == 3);
+    const void* fn = pool_kernel_for<NW, K>(lut_mode, P.merge == 3, P.merge == 3 && P.lower_build != 0);
     if (!fn) return hipErrorInvalidValue;
     void* args[] = {const_cast<AttractParams*>(&P)};
     return hipLaunchKernel(fn, grid, dim3(kPoolBlock), args, shmem, st);
 }
 template <int NW, int K>
 static hipError_t configure_pool_nk(int lut_mode, dim3, size_t shmem, hipStream_t, int& blocks_per_cu) {
-    for (int cube = 0; cube < 2; ++cube) {
-        const void* fn = pool_kernel_for<NW, K>(lut_mode, cube != 0);
+    for (int cube = 0; cube < 3; ++cube) {                  // plain, cube, lower-level cube
+        const void* fn = pool_kernel_for<NW, K>(lut_mode, cube != 0, cube == 2);
         if (!fn) return hipErrorInvalidValue;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
