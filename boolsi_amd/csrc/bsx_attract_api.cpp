@@ -440,7 +440,8 @@ void advance_first(DevSpace& sp, const bsx_index& first, uint64_t delta) {
 // hipStreamSynchronize behind a DMA copy, whose wake-up cost tens of microseconds per call.  BSX_SPIN_WAIT=0: the
 // plain copy + wait.
 int fetch_counters(bsx_handle h, uint32_t n_blocks) {
-    static const bool spin = !(std::getenv("BSX_SPIN_WAIT") && std::getenv("BSX_SPIN_WAIT")[0] == '0');
+    const char* spin_env = std::getenv("BSX_SPIN_WAIT");
+    const bool spin = !(spin_env && spin_env[0] == '0');
     if (!spin) {
         HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters) * n_blocks, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -396,7 +396,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         // the bookkeeping of an outcome (a 128-bit product, the caps) is some fifty instructions, which per batch and
         // outcome was half of what a batch of one-update classes executed.
         uint32_t* const wave_cnt = wave_base;
-        constexpr int B = 2;
+#ifndef BSX_LOWER_BATCHES
+#define BSX_LOWER_BATCHES 2
+#endif
+        constexpr int B = BSX_LOWER_BATCHES;
         for (;;) {
             if (q.next == q.end) {
                 if (!q.more) break;

@@ -19,7 +19,7 @@ from boolsi_amd.input import parse_input_text
 
 pytestmark = pytest.mark.gpu
 CORES = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-KNOBS = ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP')
+KNOBS = ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_LOWER', 'BSX_SPIN_WAIT')
 
 
 @pytest.fixture()
@@ -192,6 +192,23 @@ def test_attract2_equals_attract_block_by_block_and_counts_syncs(eng):
     assert merge_tables([ragged.table, head.table]) == merge_tables([one.table, tail.table])
     with pytest.raises(Exception):                                          # past the end of the 2^64 space
         eng.attract2((1 << 64) - 5, 6, 4096)
+
+
+@pytest.mark.parametrize('knob', ['BSX_CUBE_LOWER', 'BSX_SPIN_WAIT'])
+def test_the_general_build_and_the_plain_wait_give_the_same_tables(eng, knob):
+    """The lower levels through the general cube build (BSX_CUBE_LOWER=0) and the counters by copy + wait instead of
+    k_publish + spinning (BSX_SPIN_WAIT=0): same tables, same reference step counts."""
+    cases = [(synth.north_star_yaml(), 4096, (0x0123456789ABCDEF >> 52) << 52, 1 << 52), (chain_yaml(), np.inf, 0, 1 << 63),
+             (ring_yaml(), np.inf, 0, 1 << 56)]
+    for text, max_t, first, count in cases:
+        setup(eng, text, max_t)
+        eng.attract2(first, min(count, 1 << 30), max_t)
+        a = eng.attract2(first, count, max_t)
+        os.environ[knob] = '0'
+        b = eng.attract2(first, count, max_t)
+        os.environ.pop(knob)
+        assert merge_tables([a.table]) == merge_tables([b.table])
+        assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
 
 
 def test_north_star_whole_space_in_one_call(eng):
