@@ -165,7 +165,7 @@ def main():
         assert sum(e[1] for e in merged.values()) <= problems
         # roofline of the dominant kernel (the top-level k_attract_pool launch of every step), rank 0, measured live:
         # HIP events around those launches, the updates they executed from their own counters
-        kernel = 'k_attract_pool<{},{},{},true>'.format(info['state_words32'], info['mux_slots'], info['lut_mode'])
+        kernel = 'k_attract_pool<{},{},{},true,false>'.format(info['state_words32'], info['mux_slots'], info['lut_mode'])
         avg_launch_s = dom_ms / 1e3 / dom_launches
         upd_per_launch = dom_exec / dom_launches
         alg_bytes_per_launch = upd_per_launch * n * BYTES_PER_NODE_UPDATE

@@ -124,7 +124,7 @@ def test_bench_two_ranks_as_child_processes_equal_one_rank(tmp_path):
     one, table1 = run(1, 6, 2, {}, 'one.json')                                       # the same blocks on one rank
     assert two['n_gpus'] == 2 and 'socket' in two['config']['merge'] and one['n_gpus'] == 1
     assert table2 == table1 and len(table1) == 2
-    assert two['roofline']['kernel'] == 'k_attract_pool<2,2,1,true>'
+    assert two['roofline']['kernel'] == 'k_attract_pool<2,2,1,true,false>'
     assert abs(two['attractors_per_s'] / (6 * 2 ** 48 / (two['ms_per_step'] * 3e-3)) - 1) < 1e-6
     # RCCL cannot serve two ranks on one device: no flag, no downgrade -- every rank exits non-zero
     codes, outs = run(2, 1, 1, {}, 'never.json', expect_ok=False)

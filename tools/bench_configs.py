@@ -52,7 +52,12 @@ def roofline(bytes_moved, kernel_ms, bound='hbm-normalised', note=None, pmc_key=
         fr = {k[:-10]: v for k, v in ib.items() if k.endswith('_busy_frac')}
         r['traffic'] = pmc.get('hbm_bytes_per_launch')
         r['traffic_source'] = 'profiles/r03_pmc_{}.json (separate --pmc passes, kernel {})'.format(pmc_key, pmc.get('kernel'))
-        if fr:
+        if fr and max(fr.values()) < 0.5 and ib.get('wave_wait_frac', 0) > 0.5:
+            # no unit is even half busy and the waves mostly wait: a latency-bound launch (short, one dependent chain per lane)
+            r['hbm_normalised'] = {'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS}
+            r.update({'bound': 'latency (waves waiting {:.0%} of their cycles)'.format(ib['wave_wait_frac']), 'frac': max(fr.values()),
+                      'achieved': max(fr.values()), 'peak': 1.0, 'unit': 'busiest unit\'s busy fraction of the launch (PMC)', 'busy_fractions': fr})
+        elif fr:
             unit = max(fr, key=fr.get)
             r['hbm_normalised'] = {'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS}
             r.update({'bound': {'valu': 'valu-issue', 'salu': 'salu-issue', 'lds': 'lds-pipeline'}[unit], 'frac': min(fr[unit], 1.0),

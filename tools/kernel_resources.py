@@ -25,11 +25,13 @@ CXXFILT = 'c++filt'
 
 # what the measured configurations launch (kernel name prefix -> who)
 LAUNCHED = {
-    'bsx::k_attract_pool<2, 2, 1, true>': 'bench / north star, config 4 discovery (n = 64, K = 2): cube cascade',
-    'bsx::k_attract_pool<2, 2, 1, false>': 'north star: ragged ends, plain tiles',
+    'bsx::k_attract_pool<2, 2, 1, true, false>': 'bench / north star (n = 64, K = 2): top level of the cube cascade (the dominant launch)',
+    'bsx::k_attract_pool<2, 2, 1, true, true>': 'bench / north star: lower levels of the cascade',
+    'bsx::k_attract_pool<2, 2, 1, false, false>': 'north star: ragged ends, plain tiles',
     'bsx::k_attract<2, 2, 1>': 'north star / config 4: discovery, unresolved classes',
-    'bsx::k_attract_pool<1, 2, 1, true>': 'config 3 (n = 32, K = 2), cambium2 (n = 30, K <= 4 -> see K = 4 row): cube cascade',
-    'bsx::k_attract_pool<1, 4, 1, true>': 'config 2: cambium2 (n = 30, k_mux = 4)',
+    'bsx::k_attract_pool<1, 2, 1, true, false>': 'config 3 (n = 32, K = 2): cube cascade, top level',
+    'bsx::k_attract_pool<1, 2, 1, true, true>': 'config 3: cube cascade, lower levels',
+    'bsx::k_attract_pool<1, 4, 1, true, false>': 'config 2: cambium2 (n = 30, k_mux = 4): one cube pass at depth 5',
     'bsx::k_attract<1, 4, 1>': 'config 2: cambium2 discovery',
     'bsx::k_attract<1, 2, 1>': 'config 3: discovery',
     'bsx::k_target<2, 2, 1>': 'config 4 (n = 64, K = 2 target)',
