@@ -50,18 +50,19 @@ hipError_t launch_publish(const uint32_t* src, uint32_t* host_dst, uint32_t word
     return hipGetLastError();
 }
 
-#define BSX_POOL_DECL(NWV)                                                                                             \
-    hipError_t launch_pool_nw##NWV(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P); \
-    hipError_t configure_pool_nw##NWV(int k, int lut_mode, size_t shmem, int* blocks_per_cu);                         \
-    hipError_t launch_life_nw##NWV(int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
-BSX_POOL_DECL(1) BSX_POOL_DECL(2) BSX_POOL_DECL(4) BSX_POOL_DECL(8)
+#define BSX_POOL_DECL(TAG)                                                                                             \
+    hipError_t launch_pool_nw##TAG(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P); \
+    hipError_t configure_pool_nw##TAG(int k, int lut_mode, size_t shmem, int* blocks_per_cu);                         \
+    hipError_t launch_life_nw##TAG(int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
+BSX_POOL_DECL(1) BSX_POOL_DECL(2) BSX_POOL_DECL(4a) BSX_POOL_DECL(4b) BSX_POOL_DECL(8a) BSX_POOL_DECL(8b) BSX_POOL_DECL(8c)
 
+// (the wide states are built in several translation units each: odd / even numbers of predecessor slots, K = 6 at 8 words apart)
 hipError_t launch_attract_pool(int nw, int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) {
     switch (nw) {
         case 1: return launch_pool_nw1(k, lut_mode, grid, shmem, st, P);
         case 2: return launch_pool_nw2(k, lut_mode, grid, shmem, st, P);
-        case 4: return launch_pool_nw4(k, lut_mode, grid, shmem, st, P);
-        case 8: return launch_pool_nw8(k, lut_mode, grid, shmem, st, P);
+        case 4: return (k & 1) ? launch_pool_nw4a(k, lut_mode, grid, shmem, st, P) : launch_pool_nw4b(k, lut_mode, grid, shmem, st, P);
+        case 8: return k == 6 ? launch_pool_nw8c(k, lut_mode, grid, shmem, st, P) : (k & 1) ? launch_pool_nw8a(k, lut_mode, grid, shmem, st, P) : launch_pool_nw8b(k, lut_mode, grid, shmem, st, P);
         default: return hipErrorInvalidValue;
     }
 }
@@ -69,8 +70,8 @@ hipError_t configure_attract_pool(int nw, int k, int lut_mode, size_t shmem, int
     switch (nw) {
         case 1: return configure_pool_nw1(k, lut_mode, shmem, blocks_per_cu);
         case 2: return configure_pool_nw2(k, lut_mode, shmem, blocks_per_cu);
-        case 4: return configure_pool_nw4(k, lut_mode, shmem, blocks_per_cu);
-        case 8: return configure_pool_nw8(k, lut_mode, shmem, blocks_per_cu);
+        case 4: return (k & 1) ? configure_pool_nw4a(k, lut_mode, shmem, blocks_per_cu) : configure_pool_nw4b(k, lut_mode, shmem, blocks_per_cu);
+        case 8: return k == 6 ? configure_pool_nw8c(k, lut_mode, shmem, blocks_per_cu) : (k & 1) ? configure_pool_nw8a(k, lut_mode, shmem, blocks_per_cu) : configure_pool_nw8b(k, lut_mode, shmem, blocks_per_cu);
         default: return hipErrorInvalidValue;
     }
 }
@@ -78,8 +79,8 @@ hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hip
     switch (nw) {
         case 1: return launch_life_nw1(k, lut_mode, shmem, st, P);
         case 2: return launch_life_nw2(k, lut_mode, shmem, st, P);
-        case 4: return launch_life_nw4(k, lut_mode, shmem, st, P);
-        case 8: return launch_life_nw8(k, lut_mode, shmem, st, P);
+        case 4: return (k & 1) ? launch_life_nw4a(k, lut_mode, shmem, st, P) : launch_life_nw4b(k, lut_mode, shmem, st, P);
+        case 8: return k == 6 ? launch_life_nw8c(k, lut_mode, shmem, st, P) : (k & 1) ? launch_life_nw8a(k, lut_mode, shmem, st, P) : launch_life_nw8b(k, lut_mode, shmem, st, P);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1028,20 +1028,61 @@ static hipError_t configure_pool_nk(int lut_mode, dim3, size_t shmem, hipStream_
 
 }  // namespace bsx
 
-// One translation unit per state width: BSX_POOL_TU(2) defines launch_pool_nw2 / configure_pool_nw2 / launch_life_nw2.
-#define BSX_POOL_TU(NWV)                                                                                              \
+// One translation unit per state width -- two for the wide states, whose instantiations take minutes to compile: odd and
+// even numbers of predecessor slots (BSX_POOL_KMASK, bit k = instantiate K = k).  BSX_POOL_TU(2, ) defines launch_pool_nw2 /
+// configure_pool_nw2 / launch_life_nw2; BSX_POOL_TU(8, a) launch_pool_nw8a ...
+#ifndef BSX_POOL_KMASK
+#define BSX_POOL_KMASK 0x7E
+#endif
+#if BSX_POOL_KMASK & (1 << 1)
+#define BSX_PK1(FN, NWV) case 1: return FN<NWV, 1>(lut_mode, grid, shmem, st, P);
+#else
+#define BSX_PK1(FN, NWV)
+#endif
+#if BSX_POOL_KMASK & (1 << 2)
+#define BSX_PK2(FN, NWV) case 2: return FN<NWV, 2>(lut_mode, grid, shmem, st, P);
+#else
+#define BSX_PK2(FN, NWV)
+#endif
+#if BSX_POOL_KMASK & (1 << 3)
+#define BSX_PK3(FN, NWV) case 3: return FN<NWV, 3>(lut_mode, grid, shmem, st, P);
+#else
+#define BSX_PK3(FN, NWV)
+#endif
+#if BSX_POOL_KMASK & (1 << 4)
+#define BSX_PK4(FN, NWV) case 4: return FN<NWV, 4>(lut_mode, grid, shmem, st, P);
+#else
+#define BSX_PK4(FN, NWV)
+#endif
+#if BSX_POOL_KMASK & (1 << 5)
+#define BSX_PK5(FN, NWV) case 5: return FN<NWV, 5>(lut_mode, grid, shmem, st, P);
+#else
+#define BSX_PK5(FN, NWV)
+#endif
+#if BSX_POOL_KMASK & (1 << 6)
+#define BSX_PK6(FN, NWV) case 6: return FN<NWV, 6>(lut_mode, grid, shmem, st, P);
+#else
+#define BSX_PK6(FN, NWV)
+#endif
+#define BSX_POOL_DISPATCH_K(FN, NWV)                                                                                  \
+    switch (k) {                                                                                                      \
+        BSX_PK1(FN, NWV) BSX_PK2(FN, NWV) BSX_PK3(FN, NWV) BSX_PK4(FN, NWV) BSX_PK5(FN, NWV) BSX_PK6(FN, NWV)          \
+        default: return hipErrorInvalidValue;                                                                         \
+    }
+
+#define BSX_POOL_TU(NWV, TAG)                                                                                         \
     namespace bsx {                                                                                                   \
-    hipError_t launch_pool_nw##NWV(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) { \
-        BSX_DISPATCH_K(launch_pool_nk, NWV)                                                                           \
+    hipError_t launch_pool_nw##NWV##TAG(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const AttractParams& P) { \
+        BSX_POOL_DISPATCH_K(launch_pool_nk, NWV)                                                                      \
     }                                                                                                                 \
-    hipError_t configure_pool_nw##NWV(int k, int lut_mode, size_t shmem, int* blocks_per_cu) {                        \
+    hipError_t configure_pool_nw##NWV##TAG(int k, int lut_mode, size_t shmem, int* blocks_per_cu) {                   \
         const dim3 grid(1);                                                                                           \
         const hipStream_t st = nullptr;                                                                               \
         int& P = *blocks_per_cu;                                                                                      \
-        BSX_DISPATCH_K(configure_pool_nk, NWV)                                                                        \
+        BSX_POOL_DISPATCH_K(configure_pool_nk, NWV)                                                                   \
     }                                                                                                                 \
-    hipError_t launch_life_nw##NWV(int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P) {      \
+    hipError_t launch_life_nw##NWV##TAG(int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P) { \
         const dim3 grid(1);                                                                                           \
-        BSX_DISPATCH_K(launch_life_nk, NWV)                                                                           \
+        BSX_POOL_DISPATCH_K(launch_life_nk, NWV)                                                                      \
     }                                                                                                                 \
     }
