@@ -39,11 +39,18 @@ def main():
     empty = comm.gather_concat(np.zeros((0, 2), np.uint32))
     # one rank with more rows than the single-collective fast path carries: second collective
     big = comm.gather_concat(np.arange(comm.rank * 1000, comm.rank * 1000 + (300 if comm.rank == 1 else 3), dtype=np.uint64))
+    # more records on one rank than the single collective's slots: every rank sees it in the headers and the collective is repeated
+    huge = comm.gather_concat(np.arange(comm.rank * 10000, comm.rank * 10000 + (3000 if comm.rank == comm.world - 1 else 2), dtype=np.uint64))
+    # wide records (bsx_attr_rec2) and sums beyond 64 bits over the control plane (JSON carries Python ints of any size)
+    wide = table_from_merged({5 + comm.rank: [16, (1 << 70) + comm.rank, (1 << 130) + 1, (1 << 200) + 3], 99: [2, 1 << 64, 7, 9]}, _lib.ATTR_REC2)
+    wide_merged = merge_tables(comm.allgather_records(wide, slots=1))
+    big_sum = comm.allreduce_sum_int([(1 << 130) + comm.rank, 1])
     comm.barrier()
     with open('{}.{}'.format(out_path, comm.rank), 'w') as f:
         json.dump({'rank': comm.rank, 'world': comm.world, 'first': first, 'count': count,
                    'merged': {str(k): v for k, v in merged.items()}, 'none': none_all, 'steps': steps_all,
-                   'slowest': slowest, 'joined': joined.tolist(), 'empty_shape': list(empty.shape), 'big': big.tolist(), 'per_rank_counts': [len(g) for g in gathered]}, f)
+                   'slowest': slowest, 'joined': joined.tolist(), 'empty_shape': list(empty.shape), 'big': big.tolist(), 'huge_len': len(huge), 'huge_tail': huge[-3:].tolist(),
+                   'wide_merged': {str(k): [str(x) for x in v] for k, v in wide_merged.items()}, 'big_sum': [str(x) for x in big_sum], 'per_rank_counts': [len(g) for g in gathered]}, f)
     comm.shutdown()
 
 

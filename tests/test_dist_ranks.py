@@ -77,6 +77,13 @@ def test_allgather_merge_equals_single_process(tmp_path, world):
             expect_joined += [[v, v, v] for v in range(lo, lo + cnt)][: (q + 1) * 5]
         assert r['joined'] == expect_joined and r['empty_shape'] == [0, 2]
         assert r['big'] == [v for q in range(world) for v in range(q * 1000, q * 1000 + (300 if q == 1 else 3))]
+        # a rank with more records than the collective's slots (the collective is repeated once, with the largest count)
+        assert r['huge_len'] == 2 * (world - 1) + 3000 and r['huge_tail'] == [(world - 1) * 10000 + v for v in (2997, 2998, 2999)]
+        # wide records: counts beyond 2^64 and sums beyond 2^128 survive packing, the collective and the merge
+        expect_wide = {str(5 + q): ['16', str((1 << 70) + q), str((1 << 130) + 1), str((1 << 200) + 3)] for q in range(world)}
+        expect_wide['99'] = ['2', str(world << 64), str(7 * world), str(9 * world)]
+        assert r['wide_merged'] == expect_wide
+        assert r['big_sum'] == [str(world * (1 << 130) + sum(range(world))), str(world)]
     assert sum(r['count'] for r in results) == 20013
 
 

@@ -193,3 +193,30 @@ def test_reference_listing_labels():
         assert str(encode_state(set(), init)[0]) == p['initial_code']
         assert sorted([n, int(v)] for n, v in fixed.items()) == p['fixed']
         assert sorted([t, n, int(v)] for t, d in pert.items() for n, v in d.items()) == p['pert']
+
+
+def test_wide_records_pack_merge_and_refuse_to_overflow():
+    """bsx_attr_rec2 on the host side: 128-bit counts, 192 / 256-bit sums through table_from_merged -> merge_tables, the
+    narrow record's overflow check, and the flat 128-bit index of the binding."""
+    import numpy as np
+    import pytest
+    from boolsi_amd import _lib
+    from boolsi_amd.attract import merge_tables, record_ints, table_from_merged
+    merged = {(1 << 200) + 5: [16, (1 << 100) + 3, (1 << 150) + 1, (1 << 250) + 9], 7: [1, 1, 0, 0]}
+    wide = table_from_merged(merged, _lib.ATTR_REC2)
+    assert wide.dtype == _lib.ATTR_REC2 and len(wide) == 2
+    assert merge_tables([wide]) == merged
+    assert merge_tables([wide, wide]) == {k: [v[0], 2 * v[1], 2 * v[2], 2 * v[3]] for k, v in merged.items()}
+    assert sorted(record_ints(a) for a in wide) == sorted((k, *v) for k, v in merged.items())
+    with pytest.raises(OverflowError):
+        table_from_merged(merged, _lib.ATTR_REC)                    # a count of 2^100 is not a bsx_attr_rec
+    with pytest.raises(OverflowError):
+        table_from_merged({1: [1, 1 << 128, 0, 0]}, _lib.ATTR_REC2)
+    narrow = table_from_merged({7: [3, (1 << 64) - 1, (1 << 64) - 2, (1 << 128) - 1]}, _lib.ATTR_REC)
+    assert merge_tables([narrow])[7] == [3, (1 << 64) - 1, (1 << 64) - 2, (1 << 128) - 1]
+    with pytest.raises(RuntimeError):
+        merge_tables([narrow, table_from_merged({7: [4, 1, 0, 0]}, _lib.ATTR_REC2)])      # one key, two lengths
+    assert int(_lib.U128.of((1 << 127) + 12345)) == (1 << 127) + 12345
+    for bad in (-1, 1 << 128):
+        with pytest.raises(ValueError):
+            _lib.U128.of(bad)
