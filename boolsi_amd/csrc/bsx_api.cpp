@@ -108,6 +108,7 @@ extern "C" int bsx_destroy(bsx_handle h) {
         if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
     }
     if (h->h_ctr_multi) (void)hipHostFree(h->h_ctr_multi);
+    if (h->h_leaf) (void)hipHostFree(h->h_leaf);
     if (h->ev_top0) (void)hipEventDestroy(h->ev_top0);
     if (h->ev_top1) (void)hipEventDestroy(h->ev_top1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -465,6 +465,37 @@ int fetch_counters(bsx_handle h, uint32_t n_blocks) {
     return BSX_OK;
 }
 
+// The depth-1 level's program (bsx_device.h: LeafProgram) for the block `c1` and the digits `added` that level adds: which
+// nodes' rules read an added digit, with which inputs.  False if the level does not qualify (too many digits or dependent
+// nodes, a dependent rule with more than kLeafMaxK inputs): the per-child pass takes it then.
+bool build_leaf_program(const bsx_engine* h, const std::vector<uint32_t>& added_digits, LeafProgram& L) {
+    const uint32_t n = h->n_nodes;
+    if (added_digits.empty() || added_digits.size() > kLeafMaxBits) return false;
+    std::memset(&L, 0, sizeof(L));
+    L.kb = (uint32_t)added_digits.size();
+    std::vector<int> digit_of(n, -1);
+    for (uint32_t q = 0; q < L.kb; ++q) {
+        const uint32_t node = h->h_any[added_digits[q]];
+        digit_of[node] = (int)q;
+        L.added[node >> 5] |= 1u << (node & 31);
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        bool dependent = false;
+        const uint32_t k = h->h_pred_offsets[i + 1] - h->h_pred_offsets[i];
+        const uint32_t* preds = h->h_pred_idx.data() + h->h_pred_offsets[i];
+        if (!((h->sp.fixmask[i >> 5] >> (i & 31)) & 1u))                 // (a fixed node's rule is a constant, model.py:45-47)
+            for (uint32_t j = 0; j < k; ++j) dependent = dependent || digit_of[preds[j]] >= 0;
+        if (!dependent) { L.indep[i >> 5] |= 1u << (i & 31); continue; }
+        if (k > kLeafMaxK || L.n_dep == kLeafMaxDeps) return false;
+        LeafDep& d = L.dep[L.n_dep++];
+        d.node = (uint16_t)i;
+        d.k = (uint16_t)k;
+        for (uint32_t j = 0; j < k; ++j) d.in[j] = digit_of[preds[j]] >= 0 ? (uint16_t)(0x8000u | (uint32_t)digit_of[preds[j]]) : (uint16_t)preds[j];
+        d.tt = (uint32_t)(h->h_tt0[i] & ((1ull << (1u << k)) - 1ull));   // inputs beyond k: their selectors are 0 (the low half)
+    }
+    return true;
+}
+
 // ---- one cube: the whole cascade as ONE chain of launches -----------------------------------------------------------
 // Level d of a block enumerates the assignments of the digits F^d still depends on (top level) or, below it, the digits
 // level d adds on top of every class the level above has listed as "near a cycle" (DESIGN.md "Deeper collapse").  How many
@@ -616,6 +647,16 @@ int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapse
                 Q.chunk = 0; Q.chunk_first = 0;
                 // the lower-level build of the kernel: no pool, no rings (its LDS is the tables alone)
                 Q.lower_build = (Q.mirror_image && !(std::getenv("BSX_CUBE_LOWER") && std::getenv("BSX_CUBE_LOWER")[0] == '0')) ? 1u : 0u;
+                // ... and at depth 1, where it qualifies, per parent instead of per child (BSX_CUBE_LEAF=0: per child)
+                if (Q.lower_build && l.depth == 1 && !(std::getenv("BSX_CUBE_LEAF") && std::getenv("BSX_CUBE_LEAF")[0] == '0')) {
+                    if (!h->h_leaf) HIPCHK(h, hipHostMalloc((void**)&h->h_leaf, sizeof(LeafProgram), hipHostMallocDefault));
+                    if (build_leaf_program(h, l.cube.rel, *h->h_leaf)) {
+                        HIPCHK(h, h->d_leaf.reserve(1));
+                        HIPCHK(h, hipMemcpyAsync(h->d_leaf.p, h->h_leaf, sizeof(LeafProgram), hipMemcpyHostToDevice, h->stream));
+                        Q.leaf = h->d_leaf.p;
+                        Q.entry_shift = 0;                  // work items = the listed entries themselves
+                    }
+                }
             }
             const size_t shmem_here = Q.lower_build ? h->shmem + (size_t)slots * h->cache_stride + 32 + pool_lower_extra_bytes(nw) : shmem;
             HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem_here, h->stream, Q));

@@ -162,6 +162,30 @@ constexpr uint32_t kMaxCubeLevels = 16;     // levels of one cascade (= Counters
 constexpr size_t kLevelDescBytes = 512;     // the descriptors' share of the counter buffer (a multiple of the Counters alignment)
 static_assert(sizeof(LevelDesc) * (kMaxCubeLevels + 1) <= kLevelDescBytes, "descriptor block");
 
+// Depth-1 level of a cascade, evaluated per PARENT instead of per child.  A listed class (parent) expands into 2^kb
+// children by the digits this level adds; all children share the parent's state except for those digits, and whether a
+// child's F(x) is a cycle state c is decided by the few nodes whose rule reads an added digit (`dep`): every other node has
+// the same value for all children -- f(parent)[i] -- which must equal c[i] or no child maps to c.  So a lane takes one
+// parent: one update of its representative, a scan of the cached cycle states for those that agree on the independent
+// nodes, and for each such state the dependent nodes' truth tables evaluated bit-sliced over the children (32 per word:
+// an added digit is a constant bit pattern, a parent bit a broadcast) -- the children that hit are a popcount.  The others
+// enter the parent's cycle with the next update (mu = 2), as in the per-child pass.
+constexpr uint32_t kLeafMaxDeps = 64;       // dependent nodes the program holds (more: the per-child pass)
+constexpr uint32_t kLeafMaxBits = 9;        // added digits (512 children = 16 words per lane)
+constexpr uint32_t kLeafMaxK = 4;           // inputs of a dependent node's rule
+struct LeafDep {
+    uint16_t in[kLeafMaxK];     // input j: 0x8000 | q = the level's added digit q (child-index bit q), else the node whose PARENT bit it is
+    uint16_t node;              // the node this rule computes
+    uint16_t k;                 // inputs, 1 .. kLeafMaxK
+    uint32_t tt;                // truth table, bit idx = output when input j is (idx >> j) & 1
+};
+struct LeafProgram {
+    uint32_t kb, n_dep;
+    uint32_t indep[kMaxW32];    // node bits whose first update does not depend on an added digit
+    uint32_t added[kMaxW32];    // node bits of the added digits
+    LeafDep dep[kLeafMaxDeps];
+};
+
 struct AttractParams {
     DevNet net;
     DevSpace sp;
@@ -231,6 +255,7 @@ struct AttractParams {
     const LevelDesc* level_in;
     uint32_t lower_build;       // cube pass: launch the lower-level build of the kernel (entries != null, the mirror as an image)
     uint32_t pad2;
+    const LeafProgram* leaf;    // lower-level build at depth 1: the children of an entry are evaluated bit-sliced (below); else null
 };
 
 // Cube collapse, ordering heuristic: how long does a flip of each relevant digit stay visible?  One thread per

@@ -83,6 +83,8 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_near_counts;    // the segments' fill counts,
     bsx::DevBuf<uint32_t> d_near_list;  // and the packed list the next level reads
     bsx::DevBuf<uint32_t> d_unres;      // cascade: unresolved classes per level (state, t, member count)
+    bsx::DevBuf<bsx::LeafProgram> d_leaf;   // cascade: the depth-1 level's per-parent program (bsx_device.h)
+    bsx::LeafProgram* h_leaf = nullptr;     // ... its pinned staging copy
     uint32_t life_cache[64] = {};       // cube passes: k_digit_lifetimes per digit, measured on the first block that needed it
     uint64_t life_valid = 0;            // (an ordering heuristic: later blocks of the problem reuse it)
     uint32_t cube_depth_cap = 0;        // 0 = no experience yet; else the deepest level that paid off on this problem

@@ -396,6 +396,115 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         // the bookkeeping of an outcome (a 128-bit product, the caps) is some fifty instructions, which per batch and
         // outcome was half of what a batch of one-update classes executed.
         uint32_t* const wave_cnt = wave_base;
+        if (P.leaf) {
+            // ---- depth-1 level evaluated per parent (bsx_device.h: LeafProgram).  Work items are the listed entries themselves.
+            const LeafProgram* const L = P.leaf;
+            const uint32_t kb = L->kb, n_dep = L->n_dep;
+            const uint32_t n_words = kb > 5u ? 1u << (kb - 5u) : 1u;                       // <= 16
+            const uint32_t word_mask = kb >= 5u ? 0xFFFFFFFFu : (1u << (1u << kb)) - 1u;    // children in a word
+            uint32_t indep[NW], added[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { indep[w] = L->indep[w]; added[w] = L->added[w]; }
+            for (;;) {
+                if (q.next == q.end) {
+                    if (!q.more) break;
+                    BSX_RARE_PARAMS(Pr);
+                    const uint64_t b = first_dyn + grab_chunk(&Pr->ctr->cursor, chunk, (int)lane);
+                    if (b >= n_items) { q.more = false; continue; }
+                    q.next = b; q.end = (b + chunk < n_items) ? b + chunk : n_items;
+                }
+                const uint64_t avail = q.end - q.next;
+                const uint32_t n = avail < 64u ? (uint32_t)avail : 64u;
+                const bool lv = lane < n;
+                uint32_t Sp[NW], Y[NW], tagp = 0;       // the parent's representative, its first update
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { Sp[w] = 0; Y[w] = 0; }
+                if (lv) {
+                    const uint32_t* ent = P.entries + (q.next + lane) * (NW + 1);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) Sp[w] = ent[w];
+                    tagp = ent[NW];
+                    net_step<NW, K>(nv, Sp, fm0, fv0, Y, has_fixed);
+                    ++nexec;
+                }
+                q.next += n;
+                uint32_t hits = 0;
+                for (uint32_t sl = 0; sl < P.cc.lds_slots; ++sl) {          // (uniform: every lane looks at the same entry)
+                    const uint32_t* e = cbase + sl * S;
+                    const uint32_t tagw = __builtin_amdgcn_readfirstlane(e[NW]);
+                    if ((tagw & kTagMask) == 0) continue;
+                    {
+                        // A cycle state inside the block is the representative of its class either as a flagged entry of its own
+                        // (its irrelevant bits cleared) or, if it has none set, as itself.  Is that class a child of this parent --
+                        // equal to the parent's representative outside the added digits?  Then one member of it has mu = 0
+                        // (the class itself is counted among the hits below, at mu = 1).
+                        uint32_t d0 = 0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) d0 |= (e[w] ^ Sp[w]) & ~added[w];
+                        if (lv && d0 == 0) {
+                            const uint32_t lam0 = lamtab[(tagw & kTagMask) - 1];
+                            account_fix(tagw, 0u, lam0, 1ll);
+                            account_fix(tagw, 1u, lam0, -1ll);
+                        }
+                        if (tagw & kTagRep) continue;
+                    }
+                    uint32_t d = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) d |= (e[w] ^ Y[w]) & indep[w];
+                    const bool ok = lv && d == 0;
+                    if (!__ballot(ok)) continue;
+                    // the children whose first update is exactly this cycle state: dependent nodes, 32 children per word
+                    uint32_t match[16];
+#pragma unroll
+                    for (int w = 0; w < 16; ++w) match[w] = (uint32_t)w < n_words ? word_mask : 0u;
+                    for (uint32_t di = 0; di < n_dep; ++di) {
+                        const LeafDep dep = L->dep[di];                     // uniform
+                        const uint32_t node = dep.node, k = dep.k;
+                        uint32_t want_bit = 0;                              // this cycle state's value of the node (uniform)
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) want_bit |= e[w] & (((node >> 5) == (uint32_t)w) ? 1u << (node & 31u) : 0u);
+                        const uint32_t want = want_bit ? 0xFFFFFFFFu : 0u;
+                        uint32_t selp[kLeafMaxK];                           // inputs that are parent bits: one broadcast per lane
+#pragma unroll
+                        for (int j = 0; j < (int)kLeafMaxK; ++j)
+                            selp[j] = ((uint32_t)j < k && !(dep.in[j] & 0x8000u)) ? 0u - get_bit<NW>(Sp, dep.in[j]) : 0u;
+#pragma unroll
+                        for (int w = 0; w < 16; ++w) {
+                            if ((uint32_t)w < n_words) {                    // uniform
+                                uint32_t sel[kLeafMaxK];
+#pragma unroll
+                                for (int j = 0; j < (int)kLeafMaxK; ++j) {
+                                    const uint32_t q_digit = dep.in[j] & 0x7FFFu;
+                                    const uint32_t pat = q_digit == 0u ? 0xAAAAAAAAu : q_digit == 1u ? 0xCCCCCCCCu : q_digit == 2u ? 0xF0F0F0F0u :
+                                                         q_digit == 3u ? 0xFF00FF00u : q_digit == 4u ? 0xFFFF0000u :
+                                                         ((((uint32_t)w >> (q_digit - 5u)) & 1u) ? 0xFFFFFFFFu : 0u);
+                                    sel[j] = (dep.in[j] & 0x8000u) ? pat : selp[j];
+                                }
+                                // mux tree over the table bits (inputs beyond k select the low half: their selector is 0)
+                                uint32_t v[1 << (kLeafMaxK - 1)];
+#pragma unroll
+                                for (int i = 0; i < (1 << (kLeafMaxK - 1)); ++i) {
+                                    const uint32_t lo = 0u - ((dep.tt >> (2 * i)) & 1u), hi = 0u - ((dep.tt >> (2 * i + 1)) & 1u);
+                                    v[i] = (sel[0] & hi) | (~sel[0] & lo);
+                                }
+#pragma unroll
+                                for (int j = 1; j < (int)kLeafMaxK; ++j)
+#pragma unroll
+                                    for (int i = 0; i < (1 << (kLeafMaxK - 1 - j)); ++i) v[i] = bfi(sel[j], v[2 * i + 1], v[2 * i]);
+                                match[w] &= ~(v[0] ^ want);
+                            }
+                        }
+                    }
+                    uint32_t n_hit = 0;
+#pragma unroll
+                    for (int w = 0; w < 16; ++w) n_hit += (uint32_t)__popc(match[w]);
+                    n_hit = ok ? n_hit : 0u;
+                    if (n_hit) atomicAdd(&wave_cnt[2u * ((tagw & kTagMask) - 1u)], n_hit);
+                    hits += n_hit;
+                }
+                if (lv) atomicAdd(&wave_cnt[2u * (tagp - 1u) + 1u], (1u << kb) - hits);
+            }
+        } else {
 #ifndef BSX_LOWER_BATCHES
 #define BSX_LOWER_BATCHES 2
 #endif
@@ -500,6 +609,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 }
             }
         }
+        }       // (per-child loop)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll

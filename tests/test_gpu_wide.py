@@ -19,7 +19,7 @@ from boolsi_amd.input import parse_input_text
 
 pytestmark = pytest.mark.gpu
 CORES = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-KNOBS = ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_LOWER', 'BSX_SPIN_WAIT')
+KNOBS = ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_LOWER', 'BSX_CUBE_LEAF', 'BSX_SPIN_WAIT')
 
 
 @pytest.fixture()
@@ -194,10 +194,11 @@ def test_attract2_equals_attract_block_by_block_and_counts_syncs(eng):
         eng.attract2((1 << 64) - 5, 6, 4096)
 
 
-@pytest.mark.parametrize('knob', ['BSX_CUBE_LOWER', 'BSX_SPIN_WAIT'])
+@pytest.mark.parametrize('knob', ['BSX_CUBE_LOWER', 'BSX_CUBE_LEAF', 'BSX_SPIN_WAIT'])
 def test_the_general_build_and_the_plain_wait_give_the_same_tables(eng, knob):
-    """The lower levels through the general cube build (BSX_CUBE_LOWER=0) and the counters by copy + wait instead of
-    k_publish + spinning (BSX_SPIN_WAIT=0): same tables, same reference step counts."""
+    """The lower levels through the general cube build (BSX_CUBE_LOWER=0), the depth-1 level per child instead of per
+    parent (BSX_CUBE_LEAF=0) and the counters by copy + wait instead of k_publish + spinning (BSX_SPIN_WAIT=0): same
+    tables, same reference step counts."""
     cases = [(synth.north_star_yaml(), 4096, (0x0123456789ABCDEF >> 52) << 52, 1 << 52), (chain_yaml(), np.inf, 0, 1 << 63),
              (ring_yaml(), np.inf, 0, 1 << 56)]
     for text, max_t, first, count in cases:
@@ -209,6 +210,62 @@ def test_the_general_build_and_the_plain_wait_give_the_same_tables(eng, knob):
         os.environ.pop(knob)
         assert merge_tables([a.table]) == merge_tables([b.table])
         assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
+
+
+@pytest.mark.parametrize('k,seed', [(1, 71), (2, 72), (3, 73), (4, 74), (4, 75)])
+@pytest.mark.parametrize('depth', ['2', '3'])
+def test_per_parent_leaf_level_on_rules_of_one_to_four_inputs(eng, k, seed, depth):
+    """The depth-1 level evaluated per parent (LeafProgram: dependent rules bit-sliced over the children) on random
+    networks whose rules have 1 .. 4 inputs, forced levels: against the per-child pass and the plain enumeration, with
+    and without tight caps (a cap between mu = 0 and mu = 1 splits a class)."""
+    text = synth.network_yaml(26, k, seed, fixed={5: '1'} if seed & 1 else None)
+    for max_t, max_len in ((np.inf, np.inf), (7, 2), (2, np.inf)):
+        setup(eng, text, max_t)
+        total = 1 << 26
+        os.environ['BSX_CUBE_DEPTH'] = depth
+        a = eng.attract(0, total, max_t, max_len)
+        os.environ['BSX_CUBE_LEAF'] = '0'
+        b = eng.attract(0, total, max_t, max_len)
+        os.environ.pop('BSX_CUBE_LEAF')
+        os.environ['BSX_CUBES'] = '0'
+        c = eng.attract(0, total, max_t, max_len)
+        os.environ.pop('BSX_CUBES')
+        os.environ.pop('BSX_CUBE_DEPTH')
+        assert merge_tables([a.table]) == merge_tables([b.table]) == merge_tables([c.table]), text
+        assert a.n_no_attractor == b.n_no_attractor == c.n_no_attractor
+        assert a.stats['state_steps'] == b.stats['state_steps'] == c.stats['state_steps']
+
+
+def canalizing_yaml(n, seed):
+    """Rules of exactly four inputs that are strongly canalizing (and / or chains, and-or forms, with negations): ordered
+    dynamics, and inside a block whose fixed digits feed them many free digits stop mattering -- cubes with levels."""
+    rng = random.Random(seed)
+    names = ['x{}'.format(i) for i in range(n)]
+    rules = {}
+    for i, v in enumerate(names):
+        a, b, c, d = [('not ' if rng.random() < 0.3 else '') + names[p] for p in rng.sample(range(n), 4)]
+        form = rng.choice(('{} and {} and {} and {}', '{} or {} or {} or {}', '({} and {}) or ({} and {})', '{} and ({} or {} or {})',
+                           '({} or {}) and ({} or {})'))
+        rules[v] = form.format(a, b, c, d)
+    return yaml_of(names, rules)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_per_parent_leaf_level_on_four_input_rules_that_collapse(eng, seed):
+    text = canalizing_yaml(40, 400 + seed)
+    for max_t, max_len in ((np.inf, np.inf), (3, np.inf)):
+        setup(eng, text, max_t)
+        for first in (0, 0x5A << 24):
+            res = []
+            for env in ({'BSX_CUBE_DEPTH': '3'}, {'BSX_CUBE_DEPTH': '3', 'BSX_CUBE_LEAF': '0'}, {'BSX_CUBES': '0'}):
+                os.environ.update(env)
+                res.append(eng.attract(first, 1 << 24, max_t, max_len))
+                for k in env:
+                    os.environ.pop(k)
+            a, b, c = res
+            assert merge_tables([a.table]) == merge_tables([b.table]) == merge_tables([c.table]), text
+            assert a.n_no_attractor == b.n_no_attractor == c.n_no_attractor
+            assert a.stats['state_steps'] == b.stats['state_steps'] == c.stats['state_steps']
 
 
 def test_north_star_whole_space_in_one_call(eng):
