@@ -72,8 +72,8 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
         (e = hipEventCreate(&h->ev_top0)) != hipSuccess || (e = hipEventCreate(&h->ev_top1)) != hipSuccess ||
-        (e = h->d_ctr_raw.alloc(kLevelDescBytes + sizeof(Counters) * kMaxCubeLevels)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&h->h_ctr, sizeof(Counters) * kMaxCubeLevels + 256, hipHostMallocDefault)) != hipSuccess) {
+        (e = h->d_ctr_raw.alloc(kLevelDescBytes + sizeof(Counters) * kMaxChainBlocks)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&h->h_ctr, sizeof(Counters) * kMaxChainBlocks + 256, hipHostMallocDefault)) != hipSuccess) {
         g_create_error = std::string("stream/event creation: ") + hipGetErrorString(e);
         if (h->h_ctr) (void)hipHostFree(h->h_ctr);
         delete h;
@@ -81,7 +81,7 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
     }
     h->d_level = reinterpret_cast<LevelDesc*>(h->d_ctr_raw.p);
     h->d_ctr = reinterpret_cast<Counters*>(h->d_ctr_raw.p + kLevelDescBytes);
-    h->h_flag = reinterpret_cast<volatile uint32_t*>(h->h_ctr + kMaxCubeLevels);
+    h->h_flag = reinterpret_cast<volatile uint32_t*>(h->h_ctr + kMaxChainBlocks);
     *h->h_flag = 0;
     const char* cc_env = std::getenv("BSX_CYCLE_CACHE");       // "0" disables the cycle-state cache (A/B runs, tests)
     h->cache_enabled = !(cc_env && cc_env[0] == '0');
@@ -109,6 +109,7 @@ extern "C" int bsx_destroy(bsx_handle h) {
     }
     if (h->h_ctr_multi) (void)hipHostFree(h->h_ctr_multi);
     if (h->h_leaf) (void)hipHostFree(h->h_leaf);
+    for (hipEvent_t e : h->ev_chain) (void)hipEventDestroy(e);
     if (h->ev_top0) (void)hipEventDestroy(h->ev_top0);
     if (h->ev_top1) (void)hipEventDestroy(h->ev_top1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -353,6 +354,9 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     HIPCHK(h, hipMemset(h->d_cc_claims.p, 0, sizeof(unsigned int) * kCycleClaimSlots));
     HIPCHK(h, hipMemset(h->d_cc_count.p, 0, sizeof(unsigned int)));
     h->fast_ok = true;
+    h->split_cache.clear();
+    h->split_learned.clear();
+    std::memset(h->near_seen, 0, sizeof(h->near_seen));
     h->cube_depth_cap = 0;
     h->life_valid = 0;
     h->image_n = ~size_t(0);

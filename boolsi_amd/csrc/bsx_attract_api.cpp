@@ -22,7 +22,8 @@ constexpr uint32_t kFastSteps = 48;             // FAST phase length (steps with
 constexpr uint32_t kFastStepsMax = 3072;
 constexpr uint64_t kProbeTile = 1ull << 22;     // lean tiles while the FAST length is being calibrated
 constexpr uint64_t kGeneralTile = 1ull << 32;   // problems per launch of the general kernel (32-bit offsets)
-constexpr uint64_t kUnresCap = 1ull << 18;      // cascade: unresolved classes a level may list
+constexpr double kLevelOverheadUs = 22.0;      // cascade: what one more level costs whatever its size (cost estimates)
+constexpr uint64_t kUnresCap = 1ull << 16;      // cascade: unresolved classes a level may list
 constexpr uint64_t kNearBytes = 1ull << 32;     // cascade: list of the classes a level hands to the level below (segments, and again
                                                 // packed: a 2^63 block of the north star lists 7.5e7 classes of 12 bytes at its top)
 
@@ -235,17 +236,21 @@ namespace bsx {
 // on a free predecessor iff flipping it changes the output for some assignment of the rule's other free
 // inputs; a digit is relevant iff its node is such a predecessor of some node (fixed nodes have constant
 // rules, model.py:45-47).  f(s) is then a function of the relevant digits alone -- exactly, not heuristically.
-void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const uint32_t* fixmask) {
+void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const uint32_t* fixmask, uint64_t fix_mask, uint64_t fix_vals) {
     if (!fixmask) fixmask = h->sp.fixmask;      // (target passes: the fixed nodes of the block's fixed-node variant)
     const uint32_t n = h->n_nodes, nw = h->net.nw;
     c.d_lo = d_lo; c.a = a; c.rel.clear(); c.ok = false;
+    const uint64_t low = a >= 64 ? ~0ull : (1ull << a) - 1ull;
+    c.fix_mask = fix_mask & low; c.fix_vals = fix_vals & c.fix_mask;
+    c.free_digits = low & ~c.fix_mask;
+    c.n_free = (uint32_t)__builtin_popcountll(c.free_digits);
     uint32_t base[kMaxW32];     // origin bits + the block's fixed digits
     for (int w = 0; w < kMaxW32; ++w) { base[w] = h->sp.origin[w]; c.umask[w] = 0; c.free_mask[w] = 0; }
     std::vector<char> is_free(n, 0), relevant(n, 0);
     for (uint32_t j = 0; j < h->sp.n_any; ++j) {
         const uint32_t node = h->h_any[j];
-        if (j < a) { is_free[node] = 1; c.free_mask[node >> 5] |= 1u << (node & 31); }
-        else if ((d_lo >> j) & 1ull) base[node >> 5] |= 1u << (node & 31);
+        if (j < a && ((c.free_digits >> j) & 1ull)) { is_free[node] = 1; c.free_mask[node >> 5] |= 1u << (node & 31); }
+        else if (j < a ? ((c.fix_vals >> j) & 1ull) != 0 : ((d_lo >> j) & 1ull) != 0) base[node >> 5] |= 1u << (node & 31);
     }
     for (uint32_t i = 0; i < n; ++i) {
         if ((fixmask[i >> 5] >> (i & 31)) & 1u) continue;
@@ -273,6 +278,7 @@ void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const u
         }
     }
     for (uint32_t j = 0; j < a; ++j) {
+        if (!((c.free_digits >> j) & 1ull)) continue;
         const uint32_t node = h->h_any[j];
         if (relevant[node]) c.rel.push_back(j);
         else c.umask[node >> 5] |= 1u << (node & 31);
@@ -315,7 +321,8 @@ void cube_levels(const bsx_engine* h, const Cube& c, uint32_t max_depth, std::ve
     std::vector<uint8_t> val(n), nval(n);       // 0 / 1 / 2 = varies
     std::vector<uint64_t> dep(n, 0), ndep(n, 0);
     for (uint32_t i = 0; i < n; ++i) val[i] = (c.base[i >> 5] >> (i & 31)) & 1u;
-    for (uint32_t j = 0; j < c.a; ++j) { const uint32_t node = h->h_any[j]; val[node] = 2; dep[node] = 1ull << j; }
+    for (uint32_t j = 0; j < c.a; ++j)
+        if ((c.free_digits >> j) & 1ull) { const uint32_t node = h->h_any[j]; val[node] = 2; dep[node] = 1ull << j; }
     out.clear();
     for (uint32_t d = 1; d <= max_depth; ++d) {
         uint64_t all = 0;
@@ -449,7 +456,8 @@ int fetch_counters(bsx_handle h, uint32_t n_blocks) {
     }
     const uint32_t seq = ++h->flag_seq ? h->flag_seq : ++h->flag_seq;       // never 0
     HIPCHK(h, launch_publish(reinterpret_cast<const uint32_t*>(h->d_ctr), reinterpret_cast<uint32_t*>(h->h_ctr),
-                             (uint32_t)(sizeof(Counters) / 4 * n_blocks), const_cast<uint32_t*>(h->h_flag), seq, h->stream));
+                             (uint32_t)(sizeof(Counters) / 4 * n_blocks), const_cast<uint32_t*>(h->h_flag), seq,
+                             reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(h->d_level) + kPublishTicketOffset), h->stream));
     uint32_t polls = 0;
     while (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
@@ -496,15 +504,6 @@ bool build_leaf_program(const bsx_engine* h, const std::vector<uint32_t>& added_
     return true;
 }
 
-// ---- one cube: the whole cascade as ONE chain of launches -----------------------------------------------------------
-// Level d of a block enumerates the assignments of the digits F^d still depends on (top level) or, below it, the digits
-// level d adds on top of every class the level above has listed as "near a cycle" (DESIGN.md "Deeper collapse").  How many
-// classes a level lists is only known on the device, so the chain is enqueued blind: k_compact_near packs the list and
-// writes its length into a LevelDesc, the next level's launch (full persistent grid) reads it there and sizes its own
-// work split.  Every level counts into its own Counters block; the host waits once, reads all blocks, and only then
-// looks at what happened: a segment overflow (-> the block is redone from a shallower top), unresolved classes
-// (attractors nobody has cached yet -> the detector runs from the listed states; if one of them sat on a cycle the
-// block is repeated with the richer cache).  Passes are accepted or discarded whole.
 struct CascadeEnv {
     const AttractParams& P;         // the call's template (network, caps, cache)
     uint64_t max_t, max_len;
@@ -512,259 +511,557 @@ struct CascadeEnv {
     DevBuf<LogRec>& d_log;
 };
 
-int run_cube(bsx_handle h, const CascadeEnv& env, const Cube& c1, bool& collapsed) {
-    collapsed = false;
-    const AttractParams& P = env.P;
-    Totals& tot = env.tot;
-    const uint64_t max_t = env.max_t, max_len = env.max_len;
-    const uint32_t nw = h->net.nw, rec_words = nw + 3;
-    const uint64_t tp = h->sp.tp_origin;            // the search starts at s(T_p); class times count from there
-    const uint64_t cap_rel = max_t == BSX_T_INF ? BSX_T_INF : max_t - tp;
-    const uint32_t cap_rel32 = (cap_rel == BSX_T_INF || cap_rel >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)cap_rel;
-    const uint32_t fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
+// What every cascade of a call shares: the time caps in the units the kernels count in, the FAST length, the deepest level.
+struct CascadeShape {
+    uint64_t tp, cap_rel;
+    uint32_t cap_rel32, fast_steps, max_depth;
+    bool forced_depth;
+};
 
-    // ---- levels: rel_mask[d - 1] = digits F^d depends on.  BSX_CUBE_DEPTH caps the top level (1 = first update only) ...
+CascadeShape cascade_shape(bsx_handle h, const CascadeEnv& env) {
+    CascadeShape sh{};
+    sh.tp = h->sp.tp_origin;            // the search starts at s(T_p); class times count from there
+    sh.cap_rel = env.max_t == BSX_T_INF ? BSX_T_INF : env.max_t - sh.tp;
+    sh.cap_rel32 = (sh.cap_rel == BSX_T_INF || sh.cap_rel >= (kStepLimit / 4)) ? 0xFFFFFFFFu : (uint32_t)sh.cap_rel;
+    sh.fast_steps = (uint32_t)std::min<uint64_t>((uint64_t)sh.cap_rel32 + 1, std::min<uint32_t>(kFastStepsMax, std::max(192u, 4 * h->fast_steps)));
+    // BSX_CUBE_DEPTH caps the top level (1 = first update only)
     uint32_t max_depth = 8;
     if (const char* e = std::getenv("BSX_CUBE_DEPTH")) max_depth = (uint32_t)std::max(1, std::min((int)kMaxCubeLevels, std::atoi(e)));
     if (h->cube_depth_cap) max_depth = std::min(max_depth, h->cube_depth_cap);
     // with a warm-up the search starts at s(T_p): classes that share F^d, d <= T_p, share every state that counts,
     // so no class has to be handed down -- one pass at the best such depth
-    if (tp) max_depth = (uint32_t)std::min<uint64_t>(max_depth, tp);
-    max_depth = std::max(1u, std::min(max_depth, fast_steps > 1 ? fast_steps - 1 : 1u));
-    std::vector<uint64_t> rel_mask;
-    cube_levels(h, c1, max_depth, rel_mask);
-    // ... and otherwise the top is the depth that minimises an estimate: 12 us per level of the chain (prologue of the
-    // launch + the packing kernel behind it; nothing waits for the host between levels) and 2^|R_d| classes x (d + 0.3)
-    // updates at 2.4e11 class updates per second, so that small blocks are not pushed through levels that save less
-    // than they cost.  (An explicit BSX_CUBE_DEPTH keeps the plain rule "fewest digits": tests force levels onto small spaces.)
-    const bool forced_depth = std::getenv("BSX_CUBE_DEPTH") != nullptr;
+    if (sh.tp) max_depth = (uint32_t)std::min<uint64_t>(max_depth, sh.tp);
+    sh.max_depth = std::max(1u, std::min(max_depth, sh.fast_steps > 1 ? sh.fast_steps - 1 : 1u));
+    // (an explicit BSX_CUBE_DEPTH keeps the plain rule "fewest digits": tests force levels onto small spaces with it)
+    sh.forced_depth = std::getenv("BSX_CUBE_DEPTH") != nullptr;
+    return sh;
+}
+
+// Estimated device time of a cascade in microseconds, so that a block is not pushed through levels that cost more than they
+// save and so that sub-blocks can be compared (plan_split).  rel_mask[d - 1] = digits F^d depends on.  The top level `top`
+// enumerates 2^r_top classes at (top + 0.3) updates each; of the classes of level d + 1 the fraction f(d + 1) is listed, and
+// each listed class has 2^(r_d - r_(d + 1)) children at level d.  Rates as measured on the north star (profiles/r03_levels.md):
+// 4.5e11 class updates per second in the per-child passes, 1.5e12 children per second in the depth-1 level per parent,
+// kLevelOverheadUs for every level that has anything to do.  f is what this handle has seen at that depth so far
+// (bsx_engine::near_seen; the top level and the levels below it apart: children of listed classes are far more often near a
+// cycle than classes at large), else a guess that grows with the depth.
+double near_fraction(const bsx_engine* h, uint32_t d, bool is_top) {
+    const double* seen = h->near_seen[is_top ? 0 : 1][std::min<uint32_t>(d, kMaxCubeLevels)];
+    if (seen[0] >= 1024.0) return std::min(1.0, seen[1] / seen[0]);
+    return is_top ? std::min(1.0, 0.0025 * std::ldexp(1.0, (int)d - 2)) : 0.1;
+}
+
+double chain_cost_us(const bsx_engine* h, const std::vector<uint64_t>& rel_mask, uint32_t top) {
+    int r_above = __builtin_popcountll(rel_mask[top - 1]);
+    double n = std::ldexp(1.0, r_above);
+    double cost = kLevelOverheadUs + n * (top + 0.3) / 4.5e5;
+    for (uint32_t d = top - 1; d >= 1; --d) {
+        const double parents = n * near_fraction(h, d + 1, d + 1 == top);
+        if (parents < 1.0) { cost += 5.0 * d; break; }                  // (launches that find an empty list)
+        const int r_d = __builtin_popcountll(rel_mask[d - 1]), kb = r_d - r_above;
+        n = parents * std::ldexp(1.0, kb);
+        cost += kLevelOverheadUs + ((d == 1 && kb >= 1 && kb <= (int)kLeafMaxBits) ? n / 1.5e6 + parents / 2.0e4 : n * (d + 0.3) / 4.5e5);
+        r_above = r_d;
+    }
+    return cost;
+}
+
+// -> the top level (depth) that minimises the estimate, and the estimate
+uint32_t choose_top(const bsx_engine* h, const CascadeShape& sh, const std::vector<uint64_t>& rel_mask, uint32_t max_depth, double* est_out = nullptr) {
     uint32_t top = 1;
     double best = 0;
-    for (uint32_t d = 1; d <= max_depth; ++d) {
-        const int r_d = __builtin_popcountll(rel_mask[d - 1]);
-        const double est = forced_depth ? (double)r_d : 12.0 * d + std::ldexp(1.0, r_d) * (d + 0.3) / 2.4e5;
+    for (uint32_t d = 1; d <= max_depth && d <= rel_mask.size(); ++d) {
+        const double est = sh.forced_depth ? (double)__builtin_popcountll(rel_mask[d - 1]) : chain_cost_us(h, rel_mask, d);
         if (d == 1 || est < best) { best = est; top = d; }
     }
-    auto level_cube = [&](uint64_t digits, bool ordered, Cube& lc) -> int {
-        lc = c1;
-        lc.rel.clear();
-        for (uint32_t j = 0; j < c1.a; ++j) if ((digits >> j) & 1ull) lc.rel.push_back(j);
-        if (ordered) if (int rc = order_cube_digits(h, lc)) return rc;
-        plan_cube(h, lc);
-        return BSX_OK;
-    };
+    if (est_out) *est_out = sh.forced_depth ? chain_cost_us(h, rel_mask, top) : best;
+    return top;
+}
 
-    for (int attempt = 0; attempt < 32; ++attempt) {
-        const double pt_plan = now_ms();
-        // every cached attractor must be in the mirror, or a class could sit on a cycle nobody recognises
-        uint32_t slots = 0;
-        h->cube_mirror = true;
-        const int rc_m = lean_mirror_slots(h, &slots, &tot);
-        h->cube_mirror = false;
-        if (rc_m) return rc_m;
-        uint64_t states = 0;
-        for (const CycleRecord& jr : h->h_journal) states += jr.length;
-        if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 4 * states > h->cache_lds_slots) return BSX_OK;
-        if (top < 1) top = 1;
-        // a pass may not have more classes than its 49-bit member counts (in units of one fresh class) can add up
-        if (__builtin_popcountll(rel_mask[top - 1]) > 47) return BSX_OK;
+// ---- one cube: the whole cascade as ONE chain of launches -----------------------------------------------------------
+// Level d of a block enumerates the assignments of the digits F^d still depends on (top level) or, below it, the digits
+// level d adds on top of every class the level above has listed as "near a cycle" (DESIGN.md "Deeper collapse").  How many
+// classes a level lists is only known on the device, so the chain is enqueued blind: k_compact_near packs the list and
+// writes its length into a LevelDesc, the next level's launch (full persistent grid) reads it there and sizes its own
+// work split.  Every level counts into its own Counters block; the host waits once -- for one chain, or for the chains of
+// all sub-blocks of a split block -- reads the blocks, and only then looks at what happened: a segment overflow (-> the
+// cube is redone from a shallower top), unresolved classes (attractors nobody has cached yet -> the detector runs from the
+// listed states; if one of them sat on a cycle the cube is repeated with the richer cache).  Passes are accepted or
+// discarded whole.
+struct ChainLevel {
+    uint32_t depth = 0, k_bits = 0, r_here = 0, unit_shift = 0;
+    bool per_parent = false;        // depth 1, evaluated per listed class (LeafProgram) instead of per child
+    Cube cube;
+};
+struct Chain {
+    Cube c1;
+    std::vector<uint64_t> rel_mask;
+    std::vector<ChainLevel> lv;     // index 0 = top (depth `top`) .. top - 1 (depth 1); empty = not eligible
+    uint32_t top = 1;
+    uint32_t ctr_base = 0;          // its levels count into counter blocks ctr_base .. ctr_base + top - 1
+    uint32_t desc_base = 0;         // ... and hand over through descriptors desc_base .. desc_base + top
+    uint32_t index = 0;             // which chain of the batch (leaf program, events)
+    dim3 top_grid;
+};
+enum ChainVerdict { kChainOk = 0, kChainLower = 1, kChainRepeat = 2, kChainGiveUp = 3 };
 
-        // ---- plan the chain: level index i = 0 (top, depth `top`) .. top - 1 (depth 1)
-        const uint32_t n_levels = top;
-        struct Level { uint32_t depth, k_bits, r_here, unit_shift; uint64_t classes; Cube cube; };
-        std::vector<Level> lv(n_levels);
-        for (uint32_t i = 0; i < n_levels; ++i) {
-            const uint32_t d = top - i;
-            const uint64_t here = rel_mask[d - 1];
-            lv[i].depth = d;
-            lv[i].r_here = (uint32_t)__builtin_popcountll(here);
-            if (int rc = level_cube(i == 0 ? here : here & ~rel_mask[d], i == 0, lv[i].cube)) return rc;
-            lv[i].k_bits = (uint32_t)lv[i].cube.rel.size();
-            lv[i].unit_shift = c1.a - lv[i].r_here;         // members of one fresh class = the unit of this level's counts
-            lv[i].classes = 0;
-        }
-        const size_t shmem = h->shmem + (size_t)slots * h->cache_stride + 32 + pool_extra_bytes(h->net.nw);
-        const Launch full = plan_persistent(h, ~0ull >> 8, shmem);         // the persistent grid (lower levels: size unknown here)
-        // classes a level may hand down: as many as the top level has (a level that lists more than that is not worth its
-        // launch: the block is redone shallower), at most what 4 GiB hold; split evenly over the workgroups' segments
-        const uint64_t list_cap = std::min<uint64_t>(kNearBytes / (4 * (nw + 1)), std::max<uint64_t>(1ull << 16, 1ull << lv[0].k_bits));
-        const uint64_t seg_cap = std::getenv("BSX_CUBE_NEAR_CAP") ? (uint64_t)std::max(1, std::atoi(std::getenv("BSX_CUBE_NEAR_CAP")))     // (tests: force the shallower restart)
-                                                                    : std::max<uint64_t>(64, list_cap / full.grid.x);
-        if (n_levels > 1) {
-            HIPCHK(h, h->d_near_seg.reserve((size_t)full.grid.x * seg_cap * (nw + 1)));      // (state + the tag of its cycle)
-            HIPCHK(h, h->d_near_counts.reserve(full.grid.x));
-            HIPCHK(h, h->d_near_list.reserve((size_t)full.grid.x * seg_cap * (nw + 1)));
-        }
-        HIPCHK(h, h->d_unres.reserve((size_t)n_levels * kUnresCap * rec_words));
+// Levels of the cascade for cube c1 from the top `top` (0: chosen by the estimate).  ch.lv stays empty if the cube does not
+// qualify (more classes at the top than the 49-bit member counts, in units of one fresh class, can add up).
+int plan_chain(bsx_handle h, const CascadeShape& sh, const Cube& c1, uint32_t top, Chain& ch) {
+    ch.c1 = c1;
+    ch.lv.clear();
+    cube_levels(h, c1, sh.max_depth, ch.rel_mask);
+    ch.top = top ? std::min<uint32_t>(top, (uint32_t)ch.rel_mask.size()) : choose_top(h, sh, ch.rel_mask, sh.max_depth);
+    if (__builtin_popcountll(ch.rel_mask[ch.top - 1]) > 47) return BSX_OK;
+    ch.lv.resize(ch.top);
+    for (uint32_t i = 0; i < ch.top; ++i) {
+        const uint32_t d = ch.top - i;
+        const uint64_t here = ch.rel_mask[d - 1], digits = i == 0 ? here : here & ~ch.rel_mask[d];
+        ChainLevel& l = ch.lv[i];
+        l.depth = d;
+        l.r_here = (uint32_t)__builtin_popcountll(here);
+        l.cube = c1;
+        l.cube.rel.clear();
+        for (uint32_t j = 0; j < c1.a; ++j) if ((digits >> j) & 1ull) l.cube.rel.push_back(j);
+        if (i == 0) if (int rc = order_cube_digits(h, l.cube)) return rc;
+        plan_cube(h, l.cube);
+        l.k_bits = (uint32_t)l.cube.rel.size();
+        l.unit_shift = c1.n_free - l.r_here;            // members of one fresh class = the unit of this level's counts
+    }
+    return BSX_OK;
+}
 
-        AttractParams Q0 = P;
-        Q0.cc.lds_slots = slots;
-        Q0.merge = 3;
-        Q0.fast_steps = fast_steps;
-        Q0.per_problem = nullptr;
-        Q0.offsets = nullptr;
-        Q0.states = nullptr;
-        Q0.log = nullptr; Q0.log_cap = 0; Q0.table = nullptr; Q0.table_mask = 0;
-        for (int w = 0; w < kMaxW32; ++w) { Q0.cube_umask[w] = c1.umask[w]; Q0.cube_free[w] = c1.free_mask[w]; }
-        if (int rc = ensure_mirror_image(h, Q0, shmem)) return rc;
+// What a batch of chains shares on the device: mirror size, grid, segment size, buffers.
+struct ChainBatch {
+    uint32_t slots = 0;
+    size_t shmem = 0;
+    Launch full{};
+    uint64_t seg_cap = 0;
+};
 
-        const double pt0 = now_ms();
-        // (descriptors and the levels' counter blocks are one stretch of memory: one fill)
-        HIPCHK(h, hipMemsetAsync(h->d_level, 0, kLevelDescBytes + sizeof(Counters) * n_levels, h->stream));
-        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-        for (uint32_t i = 0; i < n_levels; ++i) {
-            const Level& l = lv[i];
-            AttractParams Q = Q0;
-            Q.sp = l.cube.sp;
-            Q.ctr = h->d_ctr + i;
-            Q.cube_shift = 0;                               // counts in units of one fresh class (2^unit_shift problems)
-            Q.cube_depth = l.depth;
-            Q.entry_shift = l.k_bits;
-            Q.stragglers = h->d_unres.p + (size_t)i * kUnresCap * rec_words;
-            Q.stragglers_cap = kUnresCap * rec_words;
-            Q.near = l.depth > 1 ? h->d_near_seg.p : nullptr;
-            Q.near_counts = l.depth > 1 ? h->d_near_counts.p : nullptr;
-            Q.near_cap = l.depth > 1 ? seg_cap : 0;
-            dim3 grid = full.grid;
-            if (i == 0) {
-                Q.count = 1ull << l.k_bits;
-                Q.entries = nullptr;
-                Q.level_in = nullptr;
-                const Launch L = plan_persistent(h, Q.count, shmem);
-                // the top level lists into per-workgroup segments sized for the full grid: keep that grid when it lists
-                grid = L.grid;
-                const uint64_t n_waves = (uint64_t)grid.x * (kPoolBlockThreads / 64);
-                // passes under 2^28 classes: even fixed shares, no traffic on the cursor's one address (their classes
-                // cost about the same everywhere); larger ones: one piece each, the rest from the cursor
-                if (Q.count < (1ull << 28)) { Q.chunk_first = ((Q.count + n_waves - 1) / n_waves + 63) / 64 * 64; Q.chunk = 0; }
-                else { Q.chunk_first = L.chunk; Q.chunk = L.chunk; }
-                if (const char* c = std::getenv("BSX_CHUNK")) { Q.chunk = (uint32_t)std::max(64, std::atoi(c)); Q.chunk_first = Q.chunk; }
-                HIPCHK(h, hipEventRecord(h->ev_top0, h->stream));
-            } else {
-                Q.count = 0;
-                Q.entries = h->d_near_list.p;               // (packed by the k_compact_near before this launch)
-                Q.level_in = h->d_level + i;
-                Q.chunk = 0; Q.chunk_first = 0;
-                // the lower-level build of the kernel: no pool, no rings (its LDS is the tables alone)
-                Q.lower_build = (Q.mirror_image && !(std::getenv("BSX_CUBE_LOWER") && std::getenv("BSX_CUBE_LOWER")[0] == '0')) ? 1u : 0u;
-                // ... and at depth 1, where it qualifies, per parent instead of per child (BSX_CUBE_LEAF=0: per child)
-                if (Q.lower_build && l.depth == 1 && !(std::getenv("BSX_CUBE_LEAF") && std::getenv("BSX_CUBE_LEAF")[0] == '0')) {
-                    if (!h->h_leaf) HIPCHK(h, hipHostMalloc((void**)&h->h_leaf, sizeof(LeafProgram), hipHostMallocDefault));
-                    if (build_leaf_program(h, l.cube.rel, *h->h_leaf)) {
-                        HIPCHK(h, h->d_leaf.reserve(1));
-                        HIPCHK(h, hipMemcpyAsync(h->d_leaf.p, h->h_leaf, sizeof(LeafProgram), hipMemcpyHostToDevice, h->stream));
-                        Q.leaf = h->d_leaf.p;
-                        Q.entry_shift = 0;                  // work items = the listed entries themselves
-                    }
+// Mirror check + buffers for a batch of chains.  ok = false: the cached attractors do not fit the mirror (no cubes then).
+int prepare_batch(bsx_handle h, const CascadeEnv& env, const std::vector<Chain*>& chains, ChainBatch& B, bool& ok) {
+    ok = false;
+    const uint32_t nw = h->net.nw, rec_words = nw + 3;
+    // every cached attractor must be in the mirror, or a class could sit on a cycle nobody recognises
+    h->cube_mirror = true;
+    const int rc_m = lean_mirror_slots(h, &B.slots, &env.tot);
+    h->cube_mirror = false;
+    if (rc_m) return rc_m;
+    uint64_t states = 0;
+    for (const CycleRecord& jr : h->h_journal) states += jr.length;
+    if (h->h_journal.size() > (size_t)kTagAcc + kLdsAcc || 4 * states > h->cache_lds_slots) return BSX_OK;
+    B.shmem = h->shmem + (size_t)B.slots * h->cache_stride + 32 + pool_extra_bytes(nw);
+    B.full = plan_persistent(h, ~0ull >> 8, B.shmem);           // the persistent grid (lower levels: size unknown here)
+    // classes a level may hand down: as many as the largest top level has (a level that lists more than that is not worth its
+    // launch: the cube is redone shallower), at most what 4 GiB hold; split evenly over the workgroups' segments
+    uint32_t top_bits = 16, blocks = 0;
+    bool lists = false;
+    for (const Chain* ch : chains) {
+        if (ch->lv.empty()) continue;
+        top_bits = std::max(top_bits, ch->lv[0].k_bits);
+        lists = lists || ch->top > 1;
+        blocks += ch->top;
+    }
+    const uint64_t list_cap = std::min<uint64_t>(kNearBytes / (4 * (nw + 1)), 1ull << top_bits);
+    B.seg_cap = std::getenv("BSX_CUBE_NEAR_CAP") ? (uint64_t)std::max(1, std::atoi(std::getenv("BSX_CUBE_NEAR_CAP")))     // (tests: force the shallower restart)
+                                                 : std::max<uint64_t>(64, list_cap / B.full.grid.x);
+    if (lists) {
+        HIPCHK(h, h->d_near_seg.reserve((size_t)B.full.grid.x * B.seg_cap * (nw + 1)));      // (state + the tag of its cycle)
+        HIPCHK(h, h->d_near_counts.reserve(B.full.grid.x));
+        HIPCHK(h, h->d_near_list.reserve((size_t)B.full.grid.x * B.seg_cap * (nw + 1)));
+    }
+    HIPCHK(h, h->d_unres.reserve((size_t)std::max(blocks, 1u) * kUnresCap * rec_words));
+    ok = true;
+    return BSX_OK;
+}
+
+// The launches of one chain, enqueued on the handle's stream (nothing is waited for).
+int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const ChainBatch& B, Chain& ch) {
+    const uint32_t nw = h->net.nw, rec_words = nw + 3;
+    AttractParams Q0 = env.P;
+    Q0.cc.lds_slots = B.slots;
+    Q0.merge = 3;
+    Q0.fast_steps = sh.fast_steps;
+    Q0.per_problem = nullptr;
+    Q0.offsets = nullptr;
+    Q0.states = nullptr;
+    Q0.log = nullptr; Q0.log_cap = 0; Q0.table = nullptr; Q0.table_mask = 0;
+    for (int w = 0; w < kMaxW32; ++w) { Q0.cube_umask[w] = ch.c1.umask[w]; Q0.cube_free[w] = ch.c1.free_mask[w]; }
+    if (int rc = ensure_mirror_image(h, Q0, B.shmem)) return rc;
+    for (uint32_t i = 0; i < ch.top; ++i) {
+        ChainLevel& l = ch.lv[i];
+        AttractParams Q = Q0;
+        Q.sp = l.cube.sp;
+        Q.ctr = h->d_ctr + ch.ctr_base + i;
+        Q.cube_shift = 0;                               // counts in units of one fresh class (2^unit_shift problems)
+        Q.cube_depth = l.depth;
+        Q.entry_shift = l.k_bits;
+        Q.stragglers = h->d_unres.p + (size_t)(ch.ctr_base + i) * kUnresCap * rec_words;
+        Q.stragglers_cap = kUnresCap * rec_words;
+        Q.near = l.depth > 1 ? h->d_near_seg.p : nullptr;
+        Q.near_counts = l.depth > 1 ? h->d_near_counts.p : nullptr;
+        Q.near_cap = l.depth > 1 ? B.seg_cap : 0;
+        dim3 grid = B.full.grid;
+        if (i == 0) {
+            Q.count = 1ull << l.k_bits;
+            Q.entries = nullptr;
+            Q.level_in = nullptr;
+            const Launch L = plan_persistent(h, Q.count, B.shmem);
+            grid = L.grid;
+            const uint64_t n_waves = (uint64_t)grid.x * (kPoolBlockThreads / 64);
+            // passes under 2^28 classes: even fixed shares, no traffic on the cursor's one address (their classes
+            // cost about the same everywhere); larger ones: one piece each, the rest from the cursor
+            if (Q.count < (1ull << 28)) { Q.chunk_first = ((Q.count + n_waves - 1) / n_waves + 63) / 64 * 64; Q.chunk = 0; }
+            else { Q.chunk_first = L.chunk; Q.chunk = L.chunk; }
+            if (const char* c = std::getenv("BSX_CHUNK")) { Q.chunk = (uint32_t)std::max(64, std::atoi(c)); Q.chunk_first = Q.chunk; }
+            ch.top_grid = grid;
+            HIPCHK(h, hipEventRecord(h->ev_chain[2 * ch.index], h->stream));
+        } else {
+            Q.count = 0;
+            Q.entries = h->d_near_list.p;               // (packed by the k_compact_near before this launch)
+            Q.level_in = h->d_level + ch.desc_base + i;
+            Q.chunk = 0; Q.chunk_first = 0;
+            // the lower-level build of the kernel: no pool, no rings (its LDS is the tables alone)
+            Q.lower_build = (Q.mirror_image && !(std::getenv("BSX_CUBE_LOWER") && std::getenv("BSX_CUBE_LOWER")[0] == '0')) ? 1u : 0u;
+            // ... and at depth 1, where it qualifies, per parent instead of per child (BSX_CUBE_LEAF=0: per child)
+            if (Q.lower_build && l.depth == 1 && !(std::getenv("BSX_CUBE_LEAF") && std::getenv("BSX_CUBE_LEAF")[0] == '0')) {
+                LeafProgram& prog = h->h_leaf[ch.index];
+                if (build_leaf_program(h, l.cube.rel, prog)) {
+                    HIPCHK(h, hipMemcpyAsync(h->d_leaf.p + ch.index, &prog, sizeof(LeafProgram), hipMemcpyHostToDevice, h->stream));
+                    Q.leaf = h->d_leaf.p + ch.index;
+                    Q.entry_shift = 0;                  // work items = the listed entries themselves
+                    l.per_parent = true;
                 }
             }
-            const size_t shmem_here = Q.lower_build ? h->shmem + (size_t)slots * h->cache_stride + 32 + pool_lower_extra_bytes(nw) : shmem;
-            HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem_here, h->stream, Q));
-            if (i == 0) HIPCHK(h, hipEventRecord(h->ev_top1, h->stream));
-            if (l.depth > 1)
-                HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, seg_cap, nw + 1, h->d_near_list.p, h->d_level + i + 1, h->stream));
         }
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-        const double pt1 = now_ms();
-        if (int rc = fetch_counters(h, n_levels)) return rc;
-        ++tot.syncs;
-        const double pt2 = now_ms();
-        float ms = 0.f, ms_top = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) {      // (events precede k_publish: complete by now, but ask nicely)
-            HIPCHK(h, hipEventSynchronize(h->ev1));
-            HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        }
-        HIPCHK(h, hipEventElapsedTime(&ms_top, h->ev_top0, h->ev_top1));
-        g_prof[0] += pt0 - pt_plan; g_prof[1] += pt1 - pt0; g_prof[2] += pt2 - pt1; g_prof[3] += ms;
-        tot.kernel_ms += ms;
-        tot.launches += 2 * n_levels - 1;
-        tot.dominant_ms += ms_top;
-        tot.dominant_exec += h->h_ctr[0].steps_exec;
-        ++tot.dominant_launches;
+        const size_t shmem_here = Q.lower_build ? h->shmem + (size_t)B.slots * h->cache_stride + 32 + pool_lower_extra_bytes(nw) : B.shmem;
+        HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem_here, h->stream, Q));
+        if (i == 0) HIPCHK(h, hipEventRecord(h->ev_chain[2 * ch.index + 1], h->stream));
+        if (l.depth > 1)
+            HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, B.seg_cap, nw + 1, h->d_near_list.p, h->d_level + ch.desc_base + i + 1, h->stream));
+    }
+    return BSX_OK;
+}
 
-        // ---- what happened, top down
-        MergedTable pass_table;
-        u128 pass_none = 0, pass_ref = 0;
-        bool repeat = false, lower = false, give_up = false;
-        uint64_t n_entries = 0;
-        for (uint32_t i = 0; i < n_levels && !repeat && !lower; ++i) {
-            const Level& l = lv[i];
-            const Counters& c = h->h_ctr[i];
-            const uint64_t classes = i == 0 ? 1ull << l.k_bits : n_entries << l.k_bits;
-            if (i > 0 && n_entries == 0) break;
-            tot.steps_exec += c.steps_exec;
-            if (std::getenv("BSX_DEBUG")) std::fprintf(stderr, "[bsx] cube 2^%u at digit value %llu: depth %u%s, %u digits here (%u relevant), %llu classes, %llu near a cycle, %llu unresolved\n", c1.a, (unsigned long long)c1.d_lo, l.depth, i == 0 ? " (top)" : "", l.k_bits, l.r_here, (unsigned long long)classes, (unsigned long long)c.near_classes, (unsigned long long)c.straggler_classes);
-            if (c.straggler_overflow) { give_up = true; break; }    // too many unresolved classes: not a space for cubes
-            if (c.near_overflow) { top = l.depth - 1; h->cube_depth_cap = top; lower = true; break; }     // start over, shallower
-            // a level whose classes mostly sit next to a cycle only adds work: later blocks stop above it
-            if (l.depth > 1 && 2 * c.near_classes > classes) h->cube_depth_cap = l.depth - 1;
-            n_entries = c.near_classes;
-            const uint32_t us = l.unit_shift;
-            merge_cube_counters(pass_table, c, us, nw);
-            pass_none += ((u128)c.n_none << us) + (u128)(__int128)(int64_t)c.fix_none;
-            pass_ref += ((u128)c.steps_ref << us) + (u128)(__int128)(int64_t)c.fix_ref +
-                        (max_t == BSX_T_INF ? (u128)0 : (u128)((__int128)(int64_t)c.fix_capfail * (__int128)max_t));
-            const uint64_t n_unres = c.straggler_classes;
-            if (!n_unres) continue;
-            // the detector runs from each listed state: a class that was not on a cycle yet gets its exact
-            // result (all members share the rest of the trajectory); one that sits on a cycle needs that
-            // attractor in the cache -- the detector has just published it -- and the pass is repeated
-            if (n_unres > kUnresCap) { give_up = true; break; }
-            std::vector<uint32_t> recs(n_unres * rec_words);
-            HIPCHK(h, hipMemcpy(recs.data(), h->d_unres.p + (size_t)i * kUnresCap * rec_words, recs.size() * 4, hipMemcpyDeviceToHost));
-            ++tot.syncs;
-            std::vector<uint32_t> st(n_unres * nw);
-            for (uint64_t q = 0; q < n_unres; ++q) std::copy(recs.begin() + q * rec_words, recs.begin() + q * rec_words + nw, st.begin() + q * nw);
-            DevBuf<uint32_t> d_states;
-            DevBuf<ProblemRec32> d_res;
-            HIPCHK(h, d_states.upload(st));
-            HIPCHK(h, d_res.alloc(n_unres));
-            AttractParams S = P;
-            S.sp = l.cube.sp;
-            S.sp.tp_origin = 0;                     // the listed states are past the warm-up
-            S.count = n_unres;
-            S.states = d_states.p;
-            S.per_problem = d_res.p;
-            S.max_len = BSX_T_INF;
-            S.merge = 0;
-            AttractRun rs;
-            if (int rc2 = launch_attract_pass(h, S, kPassGeneral, env.d_log, nullptr, rs, tot)) return rc2;
-            tot.kernel_ms += rs.ms; ++tot.launches; tot.steps_exec += rs.ctr.steps_exec; tot.limit_hits += rs.ctr.step_limit_hits;
-            std::vector<ProblemRec32> res(n_unres);
-            HIPCHK(h, hipMemcpy(res.data(), d_res.p, n_unres * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
-            ++tot.syncs;
-            for (uint64_t q = 0; q < n_unres && !repeat; ++q) {
-                const uint32_t* rec = recs.data() + q * rec_words;
-                const uint64_t t_class = rec[nw];
-                const u128 m = (u128)(((uint64_t)rec[nw + 2] << 32) | rec[nw + 1]) << us;
-                const ProblemRec32& pr = res[q];
-                if (!pr.found) { pass_none += m; pass_ref += m * max_t; continue; }        // (finite cap, or the step limit was hit)
-                if (pr.trajectory_l == 0) { repeat = true; break; }                          // on a cycle: members' mu unknown
-                const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length, traj = tp + mu;
-                const bool found = cap_rel == BSX_T_INF || mu + lam <= cap_rel;
-                pass_ref += found ? m * (traj + lam) : m * max_t;
-                if (!found || lam > max_len) { pass_none += m; continue; }
-                WideRec& e = slot_for(pass_table, pr.key, nw, lam);
-                e.count += m;
-                e.sum_l.add_mul(m, traj);
-                e.sum_l2.add_mul(m, traj * traj);               // traj < 2^31 here (32-bit device counters)
+// What a finished chain's counter blocks (in h->h_ctr) say: its sums into pass_* (only meaningful for kChainOk).
+int evaluate_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const Chain& ch, MergedTable& pass_table,
+                   u128& pass_none, u128& pass_ref, int& verdict, uint32_t& lower_to) {
+    const AttractParams& P = env.P;
+    Totals& tot = env.tot;
+    const uint64_t max_t = env.max_t, max_len = env.max_len;
+    const uint32_t nw = h->net.nw, rec_words = nw + 3;
+    verdict = kChainOk;
+    uint64_t n_entries = 0;
+    for (uint32_t i = 0; i < ch.top; ++i) {
+        const ChainLevel& l = ch.lv[i];
+        const Counters c = h->h_ctr[ch.ctr_base + i];      // (a copy: the detector pass below reuses the first block)
+        const uint64_t classes = i == 0 ? 1ull << l.k_bits : n_entries << l.k_bits;
+        if (i > 0 && n_entries == 0) break;
+        tot.steps_exec += c.steps_exec;
+        if (std::getenv("BSX_DEBUG"))
+            std::fprintf(stderr, "[bsx] cube 2^%u (%u digits free) at digit value %llu%s: depth %u%s, %u digits here (%u relevant), %llu classes, %llu near a cycle, %llu unresolved\n",
+                         ch.c1.a, ch.c1.n_free, (unsigned long long)ch.c1.d_lo, ch.c1.fix_mask ? " [sub-block]" : "", l.depth, i == 0 ? " (top)" : l.per_parent ? " (per parent)" : "", l.k_bits, l.r_here,
+                         (unsigned long long)classes, (unsigned long long)c.near_classes, (unsigned long long)c.straggler_classes);
+        if (c.straggler_overflow) { verdict = kChainGiveUp; return BSX_OK; }      // too many unresolved classes: not a space for cubes
+        if (c.near_overflow) { verdict = kChainLower; lower_to = l.depth - 1; return BSX_OK; }     // start over, shallower
+        // a level whose classes mostly sit next to a cycle only adds work: later blocks stop above it
+        if (l.depth > 1 && 2 * c.near_classes > classes) h->cube_depth_cap = l.depth - 1;
+        n_entries = c.near_classes;
+        {
+            double* seen = h->near_seen[i == 0 ? 0 : 1][std::min<uint32_t>(l.depth, kMaxCubeLevels)];
+            seen[0] += (double)classes; seen[1] += (double)c.near_classes;
+        }
+        const uint32_t us = l.unit_shift;
+        merge_cube_counters(pass_table, c, us, nw);
+        pass_none += ((u128)c.n_none << us) + (u128)(__int128)(int64_t)c.fix_none;
+        pass_ref += ((u128)c.steps_ref << us) + (u128)(__int128)(int64_t)c.fix_ref +
+                    (max_t == BSX_T_INF ? (u128)0 : (u128)((__int128)(int64_t)c.fix_capfail * (__int128)max_t));
+        const uint64_t n_unres = c.straggler_classes;
+        if (!n_unres) continue;
+        // the detector runs from each listed state: a class that was not on a cycle yet gets its exact
+        // result (all members share the rest of the trajectory); one that sits on a cycle needs that
+        // attractor in the cache -- the detector has just published it -- and the pass is repeated
+        if (n_unres > kUnresCap) { verdict = kChainGiveUp; return BSX_OK; }
+        std::vector<uint32_t> recs(n_unres * rec_words);
+        HIPCHK(h, hipMemcpy(recs.data(), h->d_unres.p + (size_t)(ch.ctr_base + i) * kUnresCap * rec_words, recs.size() * 4, hipMemcpyDeviceToHost));
+        ++tot.syncs;
+        std::vector<uint32_t> st(n_unres * nw);
+        for (uint64_t q = 0; q < n_unres; ++q) std::copy(recs.begin() + q * rec_words, recs.begin() + q * rec_words + nw, st.begin() + q * nw);
+        DevBuf<uint32_t> d_states;
+        DevBuf<ProblemRec32> d_res;
+        HIPCHK(h, d_states.upload(st));
+        HIPCHK(h, d_res.alloc(n_unres));
+        AttractParams S = P;
+        S.sp = l.cube.sp;
+        S.sp.tp_origin = 0;                     // the listed states are past the warm-up
+        S.count = n_unres;
+        S.states = d_states.p;
+        S.per_problem = d_res.p;
+        S.max_len = BSX_T_INF;
+        S.merge = 0;
+        AttractRun rs;
+        if (int rc2 = launch_attract_pass(h, S, kPassGeneral, env.d_log, nullptr, rs, tot)) return rc2;
+        tot.kernel_ms += rs.ms; ++tot.launches; tot.steps_exec += rs.ctr.steps_exec; tot.limit_hits += rs.ctr.step_limit_hits;
+        std::vector<ProblemRec32> res(n_unres);
+        HIPCHK(h, hipMemcpy(res.data(), d_res.p, n_unres * sizeof(ProblemRec32), hipMemcpyDeviceToHost));
+        ++tot.syncs;
+        for (uint64_t q = 0; q < n_unres; ++q) {
+            const uint32_t* rec = recs.data() + q * rec_words;
+            const uint64_t t_class = rec[nw];
+            const u128 m = (u128)(((uint64_t)rec[nw + 2] << 32) | rec[nw + 1]) << us;
+            const ProblemRec32& pr = res[q];
+            if (!pr.found) { pass_none += m; pass_ref += m * max_t; continue; }        // (finite cap, or the step limit was hit)
+            if (pr.trajectory_l == 0) { verdict = kChainRepeat; return BSX_OK; }        // on a cycle: members' mu unknown
+            const uint64_t mu = t_class + pr.trajectory_l, lam = pr.length, traj = sh.tp + mu;
+            const bool found = sh.cap_rel == BSX_T_INF || mu + lam <= sh.cap_rel;
+            pass_ref += found ? m * (traj + lam) : m * max_t;
+            if (!found || lam > max_len) { pass_none += m; continue; }
+            WideRec& e = slot_for(pass_table, pr.key, nw, lam);
+            e.count += m;
+            e.sum_l.add_mul(m, traj);
+            e.sum_l2.add_mul(m, traj * traj);               // traj < 2^31 here (32-bit device counters)
+        }
+    }
+    return BSX_OK;
+}
+
+// Enqueue the chains (counter blocks and descriptors laid out one after the other), wait once, account the device time.
+int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const ChainBatch& B, std::vector<Chain*>& chains) {
+    Totals& tot = env.tot;
+    uint32_t blocks = 0, n_live = 0;
+    for (Chain* ch : chains) {
+        if (ch->lv.empty()) continue;
+        ch->ctr_base = blocks;
+        ch->desc_base = blocks + n_live;
+        ch->index = n_live++;
+        blocks += ch->top;
+    }
+    if (!n_live) return BSX_OK;
+    if (blocks > kMaxChainBlocks || n_live > kMaxChains) return fail(h, BSX_ERR_INVALID, "internal: too many chains in one batch");
+    while (h->ev_chain.size() < 2 * (size_t)n_live) {
+        hipEvent_t e = nullptr;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev_chain.push_back(e);
+    }
+    if (!h->h_leaf) HIPCHK(h, hipHostMalloc((void**)&h->h_leaf, sizeof(LeafProgram) * kMaxChains, hipHostMallocDefault));
+    HIPCHK(h, h->d_leaf.reserve(kMaxChains));
+    const double pt0 = now_ms();
+    // (descriptors and the counter blocks are one stretch of memory: one fill)
+    HIPCHK(h, hipMemsetAsync(h->d_level, 0, kLevelDescBytes + sizeof(Counters) * blocks, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (Chain* ch : chains) if (!ch->lv.empty()) if (int rc = enqueue_chain(h, env, sh, B, *ch)) return rc;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    const double pt1 = now_ms();
+    if (int rc = fetch_counters(h, blocks)) return rc;
+    ++tot.syncs;
+    const double pt2 = now_ms();
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) {      // (events precede k_publish: complete by now, but ask nicely)
+        HIPCHK(h, hipEventSynchronize(h->ev1));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    }
+    g_prof[1] += pt1 - pt0; g_prof[2] += pt2 - pt1; g_prof[3] += ms;
+    tot.kernel_ms += ms;
+    for (Chain* ch : chains) {
+        if (ch->lv.empty()) continue;
+        float ms_top = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms_top, h->ev_chain[2 * ch->index], h->ev_chain[2 * ch->index + 1]));
+        tot.launches += 2 * ch->top - 1;
+        tot.dominant_ms += ms_top;
+        tot.dominant_exec += h->h_ctr[ch->ctr_base].steps_exec;
+        ++tot.dominant_launches;
+    }
+    ++tot.launches;         // (k_publish)
+    return BSX_OK;
+}
+
+// A set of cubes (one block, or the sub-blocks of a split block): plan, enqueue all their chains, wait once, look -- and
+// again, for those whose counters ask for it, from a shallower top / with the richer cache.  The results are kept aside until
+// every cube is in; collapsed = they are in env.tot (all of them, or none).
+int run_cubes(bsx_handle h, const CascadeEnv& env, const std::vector<Cube>& cubes, bool& collapsed) {
+    collapsed = false;
+    Totals& tot = env.tot;
+    const CascadeShape sh = cascade_shape(h, env);
+    std::vector<uint32_t> top(cubes.size(), 0);             // 0: the estimate chooses
+    std::vector<char> done(cubes.size(), 0);
+    Totals part;
+    const CascadeEnv env_part{env.P, env.max_t, env.max_len, part, env.d_log};
+    auto book_device_time = [&]() {                         // (device time and launches count whether or not the results are kept)
+        tot.steps_exec += part.steps_exec; tot.kernel_ms += part.kernel_ms; tot.launches += part.launches;
+        tot.dominant_ms += part.dominant_ms; tot.dominant_exec += part.dominant_exec; tot.dominant_launches += part.dominant_launches;
+        tot.syncs += part.syncs; tot.limit_hits += part.limit_hits;
+    };
+    for (int attempt = 0; attempt < 32; ++attempt) {
+        const double pt_plan = now_ms();
+        std::vector<Chain> chains;
+        std::vector<size_t> who;
+        chains.reserve(cubes.size());
+        for (size_t i = 0; i < cubes.size(); ++i) {
+            if (done[i]) continue;
+            chains.emplace_back();
+            who.push_back(i);
+            if (int rc = plan_chain(h, sh, cubes[i], top[i], chains.back())) return rc;
+            if (chains.back().lv.empty()) { book_device_time(); return BSX_OK; }
+        }
+        if (chains.empty()) break;
+        std::vector<Chain*> ptrs;
+        uint32_t blocks = 0;
+        for (Chain& ch : chains) { ptrs.push_back(&ch); blocks += ch.top; }
+        if (blocks > kMaxChainBlocks || chains.size() > kMaxChains) { book_device_time(); return BSX_OK; }
+        ChainBatch B;
+        bool ok = false;
+        if (int rc = prepare_batch(h, env_part, ptrs, B, ok)) return rc;
+        if (!ok) { book_device_time(); return BSX_OK; }
+        g_prof[0] += now_ms() - pt_plan;
+        if (int rc = run_batch(h, env_part, sh, B, ptrs)) return rc;
+        bool repeat = false;
+        for (size_t q = 0; q < chains.size(); ++q) {
+            MergedTable pass_table;
+            u128 pass_none = 0, pass_ref = 0;
+            int verdict = kChainOk;
+            uint32_t lower_to = 0;
+            if (int rc = evaluate_chain(h, env_part, sh, chains[q], pass_table, pass_none, pass_ref, verdict, lower_to)) return rc;
+            if (verdict == kChainOk) {
+                fold_table(part.merged, pass_table);
+                part.n_none += pass_none;
+                part.steps_ref += pass_ref;
+                done[who[q]] = 1;
+            } else if (verdict == kChainLower && lower_to >= 1) {
+                top[who[q]] = lower_to;
+                h->cube_depth_cap = lower_to;
+            } else if (verdict == kChainRepeat) {
+                repeat = true;
+            } else {                                        // not a space for cubes
+                book_device_time();
+                return BSX_OK;
             }
         }
-        if (give_up) return BSX_OK;
-        if (lower) continue;
         if (repeat) {
             unsigned int known = 0;
             HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
-            ++tot.syncs;
-            if (known <= h->h_journal.size()) return BSX_OK;        // the attractor cannot be cached: no cube for this block
-            continue;                                               // (the detector pass marked the journal stale)
+            ++part.syncs;
+            // the attractor cannot be cached: no cube for this block (else: the detector pass marked the journal stale)
+            if (known <= h->h_journal.size()) { book_device_time(); return BSX_OK; }
         }
-        fold_table(tot.merged, pass_table);
-        tot.n_none += pass_none;
-        tot.steps_ref += pass_ref;
-        collapsed = true;
-        return BSX_OK;
     }
+    book_device_time();
+    for (char d : done) if (!d) return BSX_OK;
+    fold_table(tot.merged, part.merged);
+    tot.n_none += part.n_none;
+    tot.steps_ref += part.steps_ref;
+    collapsed = true;
+    return BSX_OK;
+}
+
+// ---- splitting a block into sub-blocks ---------------------------------------------------------------------------------
+// The digits F^d depends on over a whole block are the union over everything the block contains.  Fix one well-chosen digit
+// and, in a network of canalizing rules, whole sub-trees of dependence disappear in each half: the two sub-blocks together
+// have fewer classes than the block (north star, 2^63 problems: 2^32 classes at depth 4; after a dozen greedy splits
+// 2^25.4).  plan_split grows that tree greedily on the cost estimate -- at each node the digit whose two halves are cheapest
+// together, as long as that saves at least 15 % and the node is worth more than a few launches -- and returns the leaves
+// as (fix_mask, fix_vals) over the digit index.  Any tree is correct (the leaves partition the block); only speed depends
+// on it, so the tree found for the first block of a size is reused for the other blocks of that size in the space.
+struct SplitLeaf { uint64_t mask, vals; };
+constexpr uint32_t kSplitMinBits = 52;      // smaller blocks finish in less time than the extra launches of their sub-blocks take
+
+// the estimate for the (sub-)block with the digits `mask` fixed at `vals`; top_rel = the digits its top level enumerates
+double cube_cost_us(bsx_handle h, const CascadeShape& sh, uint64_t d_lo, uint32_t a_bits, uint64_t mask, uint64_t vals, uint64_t* top_rel = nullptr) {
+    Cube c;
+    std::vector<uint64_t> rel_mask;
+    build_cube(h, d_lo, a_bits, c, nullptr, mask, vals);
+    cube_levels(h, c, sh.max_depth, rel_mask);
+    double est = 0;
+    const uint32_t top = choose_top(h, sh, rel_mask, sh.max_depth, &est);
+    if (top_rel) *top_rel = rel_mask[top - 1];
+    return est;
+}
+
+void plan_split(bsx_handle h, const CascadeShape& sh, uint64_t d_lo, uint32_t a_bits, bool forced, std::vector<SplitLeaf>& leaves) {
+    leaves.clear();
+    const double min_cost_us = 3 * kLevelOverheadUs;        // below this a node is a handful of launches: not worth halving
+    std::vector<SplitLeaf> todo{{0, 0}};
+    while (!todo.empty()) {
+        const SplitLeaf nd = todo.back();
+        todo.pop_back();
+        uint64_t top_rel = 0;
+        const double here = cube_cost_us(h, sh, d_lo, a_bits, nd.mask, nd.vals, &top_rel);
+        bool split = false;
+        // (forced -- BSX_CUBE_SPLIT=1, tests: a tree of eight leaves whatever the estimates say)
+        if (forced ? leaves.size() + todo.size() + 2 <= 8 : (here > min_cost_us && leaves.size() + todo.size() + 2 <= kMaxChains)) {
+            double best = 0;
+            int best_digit = -1;
+            for (uint64_t left = top_rel; left; left &= left - 1) {
+                const int j = __builtin_ctzll(left);
+                const double both = cube_cost_us(h, sh, d_lo, a_bits, nd.mask | (1ull << j), nd.vals) +
+                                    cube_cost_us(h, sh, d_lo, a_bits, nd.mask | (1ull << j), nd.vals | (1ull << j));
+                if (best_digit < 0 || both < best) { best = both; best_digit = j; }
+            }
+            if (best_digit >= 0 && (forced || best < 0.85 * here)) {
+                todo.push_back(SplitLeaf{nd.mask | (1ull << best_digit), nd.vals});
+                todo.push_back(SplitLeaf{nd.mask | (1ull << best_digit), nd.vals | (1ull << best_digit)});
+                split = true;
+            }
+        }
+        if (!split) leaves.push_back(nd);
+    }
+}
+
+// One aligned block: as the sub-blocks of its split tree where that pays (all their chains enqueued one after the other, one
+// wait), else as one cube.  collapsed = false: the caller runs the block through the plain tiles.
+int run_block(bsx_handle h, const CascadeEnv& env, uint64_t d_lo, uint32_t a_bits, bool& collapsed) {
+    collapsed = false;
+    const CascadeShape sh = cascade_shape(h, env);
+    const char* split_env = std::getenv("BSX_CUBE_SPLIT");              // "0": no sub-blocks (A/B runs, tests); "1": whatever the size
+    const bool forced = split_env && split_env[0] == '1';
+    if (!(split_env && split_env[0] == '0') && sh.tp == 0 && (a_bits >= kSplitMinBits || forced)) {
+        // the tree grown for the first block of a size serves the others of that size too, as long as the estimate says it
+        // helps there (the high digits differ, so the dependence may); a large block that it does not help gets its own
+        std::vector<std::pair<uint64_t, uint64_t>>& tree = h->split_cache[a_bits];
+        auto estimate = [&]() {
+            double est = 0;
+            for (const auto& l : tree) est += cube_cost_us(h, sh, d_lo, a_bits, l.first, l.second);
+            return est;
+        };
+        bool experienced = false;                   // has the handle seen how many classes the levels list?
+        for (uint32_t d = 0; d <= kMaxCubeLevels; ++d) experienced = experienced || h->near_seen[0][d][0] >= 1024.0;
+        auto grow = [&]() {
+            const double t0 = now_ms();
+            std::vector<SplitLeaf> fresh;
+            plan_split(h, sh, d_lo, a_bits, forced, fresh);
+            tree.clear();
+            for (const SplitLeaf& l : fresh) tree.emplace_back(l.mask, l.vals);
+            h->split_learned[a_bits] = experienced;
+            if (std::getenv("BSX_DEBUG"))
+                std::fprintf(stderr, "[bsx] split tree for blocks of 2^%u: %zu leaves, planned in %.2f ms (%s list fractions)\n", a_bits, tree.size(),
+                             now_ms() - t0, experienced ? "measured" : "guessed");
+        };
+        const double whole = cube_cost_us(h, sh, d_lo, a_bits, 0, 0);
+        bool use = false;
+        // (a tree grown on guesses is grown again once the levels' list fractions have been measured)
+        if (tree.empty() || (experienced && !h->split_learned[a_bits])) { grow(); use = tree.size() > 1; }
+        else if (tree.size() > 1) {
+            use = forced || estimate() < 0.8 * whole;
+            if (!use && a_bits >= 60) { grow(); use = tree.size() > 1; }
+        }
+        if (use) {
+            std::vector<Cube> cubes(tree.size());
+            bool eligible = true;
+            for (size_t i = 0; i < tree.size() && eligible; ++i) {
+                build_cube(h, d_lo, a_bits, cubes[i], nullptr, tree[i].first, tree[i].second);
+                // (a sub-block that does not shrink at least fourfold has no cube path of its own: the block goes unsplit)
+                if (!cubes[i].ok || cubes[i].rel.size() + 2 > cubes[i].n_free) eligible = false;
+            }
+            if (eligible) {
+                if (int rc = run_cubes(h, env, cubes, collapsed)) return rc;
+                if (collapsed) return BSX_OK;
+            }
+        }
+    }
+    Cube c;
+    build_cube(h, d_lo, a_bits, c);
+    // worth it when the block shrinks at least fourfold (otherwise the tiles do as well and keep member masks)
+    if (c.ok && c.rel.size() + 2 <= a_bits) return run_cubes(h, env, std::vector<Cube>{c}, collapsed);
     return BSX_OK;
 }
 
@@ -980,12 +1277,9 @@ int attract_segment(bsx_handle h, const bsx_index& first, u128 count, uint64_t m
                 while (a_bits > kCubeMinBits && ((at & (((u128)1 << a_bits) - 1)) != 0 || at + ((u128)1 << a_bits) > body_end)) --a_bits;
                 a_bits = std::min(a_bits, h->sp.n_any);
                 bool collapsed = false;
-                // worth it when the block shrinks at least fourfold (otherwise the tiles do as well and keep member masks);
                 // a block that does not collapse is tried again in halves down to 2^32 problems, below that it is the tiles' turn
                 for (;;) {
-                    Cube c;
-                    build_cube(h, (uint64_t)at, a_bits, c);
-                    if (c.ok && c.rel.size() + 2 <= a_bits) if (int rc = run_cube(h, env, c, collapsed)) return rc;
+                    if (int rc = run_block(h, env, (uint64_t)at, a_bits, collapsed)) return rc;
                     if (collapsed || a_bits <= 32) break;
                     --a_bits;
                 }

@@ -158,9 +158,12 @@ struct LevelDesc {
     unsigned int abort;             // a segment of the level above overflowed: the list is incomplete, the block is redone shallower
     unsigned int pad;
 };
-constexpr uint32_t kMaxCubeLevels = 16;     // levels of one cascade (= Counters blocks / descriptors per call)
-constexpr size_t kLevelDescBytes = 512;     // the descriptors' share of the counter buffer (a multiple of the Counters alignment)
-static_assert(sizeof(LevelDesc) * (kMaxCubeLevels + 1) <= kLevelDescBytes, "descriptor block");
+constexpr uint32_t kMaxCubeLevels = 16;     // levels of one cascade
+constexpr uint32_t kMaxChains = 48;         // cascades (sub-blocks of a split block) enqueued behind one wait
+constexpr uint32_t kMaxChainBlocks = 160;   // ... and their levels together = Counters blocks per wait
+constexpr size_t kLevelDescBytes = 3584;    // the descriptors' share of the counter buffer (a multiple of the Counters alignment)
+constexpr size_t kPublishTicketOffset = kLevelDescBytes - 16;   // k_publish's ticket counter lives at the end of that share
+static_assert(sizeof(LevelDesc) * (kMaxChainBlocks + kMaxChains + 1) <= kPublishTicketOffset && kLevelDescBytes % 256 == 0, "descriptor block");
 
 // Depth-1 level of a cascade, evaluated per PARENT instead of per child.  A listed class (parent) expands into 2^kb
 // children by the digits this level adds; all children share the parent's state except for those digits, and whether a
@@ -171,7 +174,7 @@ static_assert(sizeof(LevelDesc) * (kMaxCubeLevels + 1) <= kLevelDescBytes, "desc
 // an added digit is a constant bit pattern, a parent bit a broadcast) -- the children that hit are a popcount.  The others
 // enter the parent's cycle with the next update (mu = 2), as in the per-child pass.
 constexpr uint32_t kLeafMaxDeps = 64;       // dependent nodes the program holds (more: the per-child pass)
-constexpr uint32_t kLeafMaxBits = 9;        // added digits (512 children = 16 words per lane)
+constexpr uint32_t kLeafMaxBits = 14;       // digits the level may add (the children are evaluated 512 at a time)
 constexpr uint32_t kLeafMaxK = 4;           // inputs of a dependent node's rule
 struct LeafDep {
     uint16_t in[kLeafMaxK];     // input j: 0x8000 | q = the level's added digit q (child-index bit q), else the node whose PARENT bit it is

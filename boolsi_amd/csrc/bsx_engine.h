@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bsx.h"
@@ -87,6 +89,7 @@ struct bsx_engine {
     bsx::LeafProgram* h_leaf = nullptr;     // ... its pinned staging copy
     uint32_t life_cache[64] = {};       // cube passes: k_digit_lifetimes per digit, measured on the first block that needed it
     uint64_t life_valid = 0;            // (an ordering heuristic: later blocks of the problem reuse it)
+    double near_seen[2][bsx::kMaxCubeLevels + 1][2] = {};   // cascade: [top level / below][depth] -> classes seen, of them near a cycle
     uint32_t cube_depth_cap = 0;        // 0 = no experience yet; else the deepest level that paid off on this problem
     bsx::DevBuf<uint32_t> d_life;       // cube collapse: per-digit influence lifetimes (ordering heuristic)
     bsx::DevBuf<uint32_t> d_lut, d_masks, d_wide_desc, d_wide_preds, d_wide_tt;
@@ -117,7 +120,10 @@ struct bsx_engine {
     bsx::Counters* h_ctr = nullptr;
     volatile uint32_t* h_flag = nullptr;    // (behind h_ctr in the same pinned allocation)
     uint32_t flag_seq = 0;
-    hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;    // around the top-level (dominant) launch of a cascade
+    hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;
+    std::vector<hipEvent_t> ev_chain;                   // pairs around the top-level (dominant) launch of every chain of a batch
+    std::map<uint32_t, bool> split_learned;             // ... grown with measured list fractions (near_seen), not guesses
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> split_cache;    // block size -> leaves (fix mask, values) of its split tree
     // independent launches of one call side by side (target's cube passes): auxiliary streams, one counter block per launch
     hipStream_t aux[8] = {};
     hipEvent_t aux_done[8] = {};

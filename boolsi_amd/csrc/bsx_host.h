@@ -30,7 +30,8 @@ size_t pool_extra_bytes(uint32_t nw);
 size_t pool_lower_extra_bytes(uint32_t nw);
 hipError_t launch_digit_lifetimes(int nw, int k, int lut_mode, size_t shmem, hipStream_t st, const LifetimeParams& P);
 hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw, uint32_t* out, LevelDesc* desc, hipStream_t stream);
-hipError_t launch_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq, hipStream_t stream);
+hipError_t launch_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq, unsigned int* ticket,
+                          hipStream_t stream);
 hipError_t launch_fg_succ(int k, int lut_mode, dim3 grid, size_t shmem, hipStream_t st, const DevNet& net, const DevSpace& sp,
                           uint64_t n_states, uint32_t* succ, uint32_t warm_steps);
 hipError_t launch_fg_double(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t cus, hipStream_t st);
@@ -219,6 +220,11 @@ inline Key8 key8(const uint32_t* words) { Key8 k; std::copy(words, words + kMaxW
 struct Cube {
     uint64_t d_lo;              // first digit value (multiple of 2^a)
     uint32_t a;                 // log2 of the problems in the block
+    // A SUB-BLOCK fixes some of the block's a lowest digits as well (fix_mask / fix_vals over the digit index): the block is the
+    // disjoint union of the sub-blocks of a split, and fixing a well-chosen digit makes many others irrelevant
+    // (bsx_attract_api.cpp: plan_split).  free_digits = the digits that vary, n_free of them: the sub-block has 2^n_free problems.
+    uint64_t fix_mask = 0, fix_vals = 0, free_digits = 0;
+    uint32_t n_free = 0;
     std::vector<uint32_t> rel;  // relevant digits: ascending from build_cube, then in class-index bit order
     uint32_t base[kMaxW32];     // the block's fixed bits, free bits zero
     DevSpace sp;                // enumeration of the relevant digits' assignments (plan_cube)
@@ -226,7 +232,8 @@ struct Cube {
     uint32_t free_mask[kMaxW32];
     bool ok = false;            // false: more deposit runs than the kernels take
 };
-void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const uint32_t* fixmask = nullptr);
+void build_cube(const bsx_engine* h, uint64_t d_lo, uint32_t a, Cube& c, const uint32_t* fixmask = nullptr,
+                uint64_t fix_mask = 0, uint64_t fix_vals = 0);
 void plan_cube(const bsx_engine* h, Cube& c);
 
 constexpr uint32_t kCubeMinBits = 16;           // cube collapse: smallest aligned block handled as a cube

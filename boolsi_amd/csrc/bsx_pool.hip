@@ -13,20 +13,20 @@ constexpr int kPoolWaves = kPoolBlockThreads / 64;
 __global__ __launch_bounds__(256) void k_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg,
                                                       uint64_t cap, uint32_t nw, uint32_t* out, LevelDesc* desc) {
     __shared__ unsigned long long before;
+    const uint32_t listed = counts[blockIdx.x];
+    if (listed > cap && threadIdx.x == 0) atomicOr(&desc->abort, 1u);      // a segment was too small: the list is incomplete
+    if (listed == 0 && blockIdx.x != n_seg - 1) return;                    // (most segments of a short list)
     if (threadIdx.x == 0) before = 0;
     __syncthreads();
     unsigned long long part = 0;
     for (uint32_t g = threadIdx.x; g < blockIdx.x; g += blockDim.x) part += counts[g] < cap ? counts[g] : cap;
     if (part) atomicAdd(&before, part);
     __syncthreads();
-    const uint64_t mine = counts[blockIdx.x] < cap ? counts[blockIdx.x] : cap;
+    const uint64_t mine = listed < cap ? listed : cap;
     const uint32_t* src = seg + (uint64_t)blockIdx.x * cap * nw;
     uint32_t* dst = out + before * nw;
     for (uint64_t i = threadIdx.x; i < mine * nw; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x == 0) {
-        if (counts[blockIdx.x] > cap) atomicOr(&desc->abort, 1u);      // a segment was too small: the list is incomplete
-        if (blockIdx.x == n_seg - 1) desc->n_entries = before + mine;
-    }
+    if (threadIdx.x == 0 && blockIdx.x == n_seg - 1) desc->n_entries = before + mine;
 }
 
 hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint32_t n_seg, uint64_t cap, uint32_t nw,
@@ -38,15 +38,29 @@ hipError_t launch_compact_near(const uint32_t* seg, const uint32_t* counts, uint
 
 // Last kernel of a chain: the counter blocks -> pinned host memory, then (system-scope release) the sequence number
 // the host is spinning on (bsx_attract_api.cpp: fetch_counters).
-__global__ __launch_bounds__(256) void k_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq) {
-    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) host_dst[i] = src[i];
+__global__ __launch_bounds__(256) void k_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq,
+                                                  unsigned int* ticket) {
+    // (the blocks are multiples of 256 bytes: whole uint4s)
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(host_dst);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words / 4; i += gridDim.x * blockDim.x) d4[i] = s4[i];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        // the workgroup that finishes last raises the flag (and leaves the ticket at 0 for the next chain)
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
-hipError_t launch_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq, hipStream_t stream) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, stream, src, host_dst, words, host_flag, seq);
+hipError_t launch_publish(const uint32_t* src, uint32_t* host_dst, uint32_t words, uint32_t* host_flag, uint32_t seq, unsigned int* ticket,
+                          hipStream_t stream) {
+    const uint32_t wgs = words / 4 <= 2048 ? 1u : words / 4 <= 16384 ? 8u : 32u;       // one per 16 KiB or so
+    hipLaunchKernelGGL(k_publish, dim3(wgs), dim3(256), 0, stream, src, host_dst, words, host_flag, seq, ticket);
     return hipGetLastError();
 }
 

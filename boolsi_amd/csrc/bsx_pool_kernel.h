@@ -99,6 +99,12 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             const uint64_t n_waves = (uint64_t)gridDim.x * kPoolWaves;
             if (n_items < (1ull << 28)) { chunk_first = ((n_items + n_waves - 1) / n_waves + 63) / 64 * 64; chunk = 0; }
             else { chunk_first = 4096; chunk = 4096; }
+            // a short list keeps only some workgroups busy (wave w of workgroup g takes share w * gridDim.x + g, so those are
+            // spread over the chip): the others leave before they stage anything
+            if ((uint64_t)blockIdx.x * chunk_first >= n_items) {
+                if (threadIdx.x == 0 && P.near_counts) P.near_counts[blockIdx.x] = 0;
+                return;
+            }
         }
     }
     const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
@@ -256,12 +262,13 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
     // has at most 2^28 problems) -- the plain build keeps its registers
     using cnt_t = std::conditional_t<CUBE, unsigned long long, uint32_t>;
     uint32_t nexec = 0;
-    // work queue: every wave's first chunk is fixed (wave w of the grid takes chunk w), only the chunks after those
-    // come from the shared cursor -- a small pass has no traffic on that one address at all
+    // work queue: every wave's first chunk is fixed (wave w of workgroup g takes chunk w * gridDim.x + g: a pass with fewer
+    // chunks than waves runs on all CUs with few waves each), only the chunks after those come from the shared cursor --
+    // a small pass has no traffic on that one address at all
     const uint64_t first_dyn = (uint64_t)gridDim.x * kPoolWaves * chunk_first;
     WaveQueue q{0, 0, chunk != 0 && n_items > first_dyn};
     {
-        const uint64_t b = ((uint64_t)blockIdx.x * kPoolWaves + wave) * chunk_first;
+        const uint64_t b = ((uint64_t)wave * gridDim.x + blockIdx.x) * chunk_first;
         if (b < n_items) { q.next = b; q.end = (b + chunk_first < n_items) ? b + chunk_first : n_items; }
     }
     uint32_t head = 0, count = 0;                           // pool ring (uniform)
@@ -400,8 +407,11 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             // ---- depth-1 level evaluated per parent (bsx_device.h: LeafProgram).  Work items are the listed entries themselves.
             const LeafProgram* const L = P.leaf;
             const uint32_t kb = L->kb, n_dep = L->n_dep;
-            const uint32_t n_words = kb > 5u ? 1u << (kb - 5u) : 1u;                       // <= 16
-            const uint32_t word_mask = kb >= 5u ? 0xFFFFFFFFu : (1u << (1u << kb)) - 1u;    // children in a word
+            // (the children are taken 512 at a time: 16 words of 32; digits 9.. of the child index number the pieces)
+            const uint32_t kb_in = kb < 9u ? kb : 9u;
+            const uint32_t n_pieces = 1u << (kb - kb_in);
+            const uint32_t n_words = kb_in > 5u ? 1u << (kb_in - 5u) : 1u;                     // <= 16
+            const uint32_t word_mask = kb_in >= 5u ? 0xFFFFFFFFu : (1u << (1u << kb_in)) - 1u;  // children in a word
             uint32_t indep[NW], added[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) { indep[w] = L->indep[w]; added[w] = L->added[w]; }
@@ -454,50 +464,53 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     const bool ok = lv && d == 0;
                     if (!__ballot(ok)) continue;
                     // the children whose first update is exactly this cycle state: dependent nodes, 32 children per word
-                    uint32_t match[16];
+                    uint32_t n_hit = 0;
+                    for (uint32_t piece = 0; piece < n_pieces; ++piece) {
+                        uint32_t match[16];
 #pragma unroll
-                    for (int w = 0; w < 16; ++w) match[w] = (uint32_t)w < n_words ? word_mask : 0u;
-                    for (uint32_t di = 0; di < n_dep; ++di) {
-                        const LeafDep dep = L->dep[di];                     // uniform
-                        const uint32_t node = dep.node, k = dep.k;
-                        uint32_t want_bit = 0;                              // this cycle state's value of the node (uniform)
+                        for (int w = 0; w < 16; ++w) match[w] = (uint32_t)w < n_words ? word_mask : 0u;
+                        for (uint32_t di = 0; di < n_dep; ++di) {
+                            const LeafDep dep = L->dep[di];                     // uniform
+                            const uint32_t node = dep.node, k = dep.k;
+                            uint32_t want_bit = 0;                              // this cycle state's value of the node (uniform)
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) want_bit |= e[w] & (((node >> 5) == (uint32_t)w) ? 1u << (node & 31u) : 0u);
-                        const uint32_t want = want_bit ? 0xFFFFFFFFu : 0u;
-                        uint32_t selp[kLeafMaxK];                           // inputs that are parent bits: one broadcast per lane
+                            for (int w = 0; w < NW; ++w) want_bit |= e[w] & (((node >> 5) == (uint32_t)w) ? 1u << (node & 31u) : 0u);
+                            const uint32_t want = want_bit ? 0xFFFFFFFFu : 0u;
+                            uint32_t selp[kLeafMaxK];                           // inputs that are parent bits: one broadcast per lane
 #pragma unroll
-                        for (int j = 0; j < (int)kLeafMaxK; ++j)
-                            selp[j] = ((uint32_t)j < k && !(dep.in[j] & 0x8000u)) ? 0u - get_bit<NW>(Sp, dep.in[j]) : 0u;
+                            for (int j = 0; j < (int)kLeafMaxK; ++j)
+                                selp[j] = ((uint32_t)j < k && !(dep.in[j] & 0x8000u)) ? 0u - get_bit<NW>(Sp, dep.in[j]) : 0u;
 #pragma unroll
-                        for (int w = 0; w < 16; ++w) {
-                            if ((uint32_t)w < n_words) {                    // uniform
-                                uint32_t sel[kLeafMaxK];
+                            for (int w = 0; w < 16; ++w) {
+                                if ((uint32_t)w < n_words) {                    // uniform
+                                    const uint32_t wg = piece * 16u + (uint32_t)w;     // the word's number among all children's
+                                    uint32_t sel[kLeafMaxK];
 #pragma unroll
-                                for (int j = 0; j < (int)kLeafMaxK; ++j) {
-                                    const uint32_t q_digit = dep.in[j] & 0x7FFFu;
-                                    const uint32_t pat = q_digit == 0u ? 0xAAAAAAAAu : q_digit == 1u ? 0xCCCCCCCCu : q_digit == 2u ? 0xF0F0F0F0u :
-                                                         q_digit == 3u ? 0xFF00FF00u : q_digit == 4u ? 0xFFFF0000u :
-                                                         ((((uint32_t)w >> (q_digit - 5u)) & 1u) ? 0xFFFFFFFFu : 0u);
-                                    sel[j] = (dep.in[j] & 0x8000u) ? pat : selp[j];
+                                    for (int j = 0; j < (int)kLeafMaxK; ++j) {
+                                        const uint32_t q_digit = dep.in[j] & 0x7FFFu;
+                                        const uint32_t pat = q_digit == 0u ? 0xAAAAAAAAu : q_digit == 1u ? 0xCCCCCCCCu : q_digit == 2u ? 0xF0F0F0F0u :
+                                                             q_digit == 3u ? 0xFF00FF00u : q_digit == 4u ? 0xFFFF0000u :
+                                                             (((wg >> (q_digit - 5u)) & 1u) ? 0xFFFFFFFFu : 0u);
+                                        sel[j] = (dep.in[j] & 0x8000u) ? pat : selp[j];
+                                    }
+                                    // mux tree over the table bits (inputs beyond k select the low half: their selector is 0)
+                                    uint32_t v[1 << (kLeafMaxK - 1)];
+#pragma unroll
+                                    for (int i = 0; i < (1 << (kLeafMaxK - 1)); ++i) {
+                                        const uint32_t lo = 0u - ((dep.tt >> (2 * i)) & 1u), hi = 0u - ((dep.tt >> (2 * i + 1)) & 1u);
+                                        v[i] = (sel[0] & hi) | (~sel[0] & lo);
+                                    }
+#pragma unroll
+                                    for (int j = 1; j < (int)kLeafMaxK; ++j)
+#pragma unroll
+                                        for (int i = 0; i < (1 << (kLeafMaxK - 1 - j)); ++i) v[i] = bfi(sel[j], v[2 * i + 1], v[2 * i]);
+                                    match[w] &= ~(v[0] ^ want);
                                 }
-                                // mux tree over the table bits (inputs beyond k select the low half: their selector is 0)
-                                uint32_t v[1 << (kLeafMaxK - 1)];
-#pragma unroll
-                                for (int i = 0; i < (1 << (kLeafMaxK - 1)); ++i) {
-                                    const uint32_t lo = 0u - ((dep.tt >> (2 * i)) & 1u), hi = 0u - ((dep.tt >> (2 * i + 1)) & 1u);
-                                    v[i] = (sel[0] & hi) | (~sel[0] & lo);
-                                }
-#pragma unroll
-                                for (int j = 1; j < (int)kLeafMaxK; ++j)
-#pragma unroll
-                                    for (int i = 0; i < (1 << (kLeafMaxK - 1 - j)); ++i) v[i] = bfi(sel[j], v[2 * i + 1], v[2 * i]);
-                                match[w] &= ~(v[0] ^ want);
                             }
                         }
-                    }
-                    uint32_t n_hit = 0;
 #pragma unroll
-                    for (int w = 0; w < 16; ++w) n_hit += (uint32_t)__popc(match[w]);
+                        for (int w = 0; w < 16; ++w) n_hit += (uint32_t)__popc(match[w]);
+                    }
                     n_hit = ok ? n_hit : 0u;
                     if (n_hit) atomicAdd(&wave_cnt[2u * ((tagw & kTagMask) - 1u)], n_hit);
                     hits += n_hit;

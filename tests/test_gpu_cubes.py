@@ -25,7 +25,7 @@ def eng():
     e = Engine(0)
     yield e
     e.close()
-    for k in ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP'):
+    for k in ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_SPLIT'):
         os.environ.pop(k, None)
 
 
@@ -315,3 +315,71 @@ def test_forced_levels_with_a_warm_up(eng, depth):
     os.environ['BSX_CUBES'] = '0'
     plain = eng.attract(0, 1 << 30)
     assert len(got.table) == 39 and rows(got.table) == rows(plain.table) and got.stats['state_steps'] == plain.stats['state_steps']
+
+
+# ---- sub-blocks: a block split along well-chosen relevant digits (BSX_CUBE_SPLIT=1 forces an eight-leaf tree on any block) ----
+
+@pytest.mark.parametrize('depth', [None, '2', '4'])
+def test_sub_blocks_vs_oracle_on_the_north_star(eng, depth):
+    os.environ['BSX_CUBE_SPLIT'] = '1'
+    if depth:
+        os.environ['BSX_CUBE_DEPTH'] = depth
+    net, space = setup(eng, synth.north_star_yaml())
+    base = 0x0123456789ABCDEF & ~((1 << 28) - 1)
+    same_as_oracle(eng, net, space, base, 1 << 24)                           # (first contact with the attractors happens in sub-blocks)
+    g = same_as_oracle(eng, net, space, base + (1 << 24), 1 << 24)
+    assert g.stats['kernel_launches'] >= 8                                          # ... and there were several chains
+    same_as_oracle(eng, net, space, base + (1 << 25) + 999, (1 << 23) + 12345)
+    same_as_oracle(eng, net, space, 0, 1 << 23, max_t=12)
+
+
+@pytest.mark.parametrize('name,text,bits,log2n', [('config3', synth.config3_yaml(), 32, 22), ('n128_k2', synth.network_yaml(128, 2, 129), 128, 22),
+                                                  ('n200_k2', synth.network_yaml(200, 2, 2001), 200, 20)],
+                         ids=['config3', 'n128_k2', 'n200_k2'])
+def test_sub_blocks_vs_oracle_other_word_counts(eng, name, text, bits, log2n):
+    os.environ['BSX_CUBE_SPLIT'] = '1'
+    os.environ['BSX_CUBE_DEPTH'] = '8'
+    net, space = setup(eng, text)
+    same_as_oracle(eng, net, space, 0, 1 << log2n)
+    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << (log2n - 1)) + 99)
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_sub_blocks_equal_plain_enumeration_on_random_spaces(eng, seed):
+    """Differential fuzz of split blocks: sparse networks, fixed nodes, tight caps, forced or free depths, short
+    near-cycle lists (a sub-block restarts shallower on its own); against the plain enumeration."""
+    import random
+    rng = random.Random(8100 + seed)
+    n = rng.choice((18, 20, 22))
+    k = rng.choice((1, 2, 2, 3))
+    fixed = {rng.randrange(n): rng.choice('01')} if rng.random() < 0.3 else None
+    initial = {i: rng.choice('01') for i in rng.sample(range(n), 2)} if rng.random() < 0.3 else None
+    max_t = rng.choice((np.inf, 4096, 4096, 9, 5, 3, 1))
+    max_len = rng.choice((np.inf, np.inf, 1, 2))
+    text = synth.network_yaml(n, k, 9500 + seed, initial=initial, fixed=fixed)
+    net, space = setup(eng, text, max_t)
+    total = space.n_problems
+    count = rng.randrange(min(1 << 17, total // 2), total + 1)
+    first = rng.randrange(0, total - count + 1)
+    if rng.random() < 0.5:
+        first &= ~0xFFFF
+    os.environ['BSX_CUBE_SPLIT'] = '1'
+    depth = rng.choice((None, None, 2, 3, 4, 8))
+    if depth:
+        os.environ['BSX_CUBE_DEPTH'] = str(depth)
+    if rng.random() < 0.25:
+        os.environ['BSX_CUBE_NEAR_CAP'] = str(rng.choice((1, 7, 100)))
+    a = eng.attract(first, count, max_t, max_len)
+    os.environ['BSX_CUBES'] = '0'
+    b = eng.attract(first, count, max_t, max_len)
+    assert rows(a.table) == rows(b.table), text
+    assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
+    assert int(a.table['count'].sum()) + a.n_no_attractor == count
+
+
+def test_sub_blocks_members_that_are_cycle_states_themselves(eng):
+    """The whole space of small networks, where every cycle state is a member of some sub-block's class."""
+    os.environ['BSX_CUBE_SPLIT'] = '1'
+    for seed in (3, 11, 29):
+        net, space = setup(eng, synth.network_yaml(20, 2, 600 + seed), np.inf)
+        same_as_oracle(eng, net, space, 0, 1 << 20, max_t=np.inf)
