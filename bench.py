@@ -5,10 +5,11 @@ a synthetic 64-node network (K = 2, seed 64, every node 'any'; the 2^64 space is
 index range), at 1/2/4/8 GPUs.
 
 One "step" = one pass of the hot path (bsx_run_attract2: enumerate -> step -> detect -> aggregate) over one batch of
-2^LOG2_BATCH consecutive problem indices per GPU (default 2^56: 1/256 of the whole space), folded into the rank's running
-attractor table.  The engine runs such a batch as ONE chain of launches (DESIGN.md "Deeper collapse" / "levels chained on
-the device"): k_attract_pool per level of the cube cascade with a packing kernel in between, the top level dominant; the
-host enqueues the chain, waits once and adds up wide integers.  Weak scaling: every rank gets its own batch each step.
+2^LOG2_BATCH consecutive problem indices per GPU (default 2^60: 1/16 of the whole space, so the default 16 steps are one
+sweep's worth of problems), folded into the rank's running attractor table.  The engine runs such a batch as chains of
+launches behind ONE wait (DESIGN.md "Deeper collapse" / "levels chained on the device" / "sub-blocks"): k_attract_pool per
+level of each sub-block's cascade with a packing kernel in between, the top levels dominant; the host enqueues the chains,
+waits once and adds up wide integers.  Weak scaling: every rank gets its own batch each step.
 After the LAST step the per-rank tables are merged with one RCCL all-gather (inside the timed region; N > 1 only).
 Network tables live in HBM before the timed region; initial states are generated on the device from the index, so
 nothing crosses PCIe inside a step except a few KB of counters.
@@ -53,9 +54,9 @@ PMC_FILE = os.path.join('profiles', 'r03_pmc.json')     # written by tools/pmc_r
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--log2-batch', type=int, default=56, help='log2 of problems per GPU per step (<= 63)')
+    ap.add_argument('--log2-batch', type=int, default=60, help='log2 of problems per GPU per step (<= 63)')
     ap.add_argument('--allow-socket-merge', action='store_true', help='N > 1: if RCCL cannot be set up, merge over the TCP control plane instead of failing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-table', metavar='PATH', help='rank 0 writes the merged attractor table of the timed steps there (JSON; tests)')
@@ -106,13 +107,10 @@ def main():
     n = net.n_nodes
     info = eng.network_info()
     batch = 1 << args.log2_batch
-    n_batches = (1 << 64) // batch
     base = 0x0123456789ABCDEF & ~(batch - 1)     # somewhere inside the 2^64 space, batch aligned
-    if (args.warmup + args.steps) * comm.world > n_batches:
-        raise SystemExit('2^64 / 2^{} = {} batches do not cover {} steps x {} ranks: lower --log2-batch'.format(
-            args.log2_batch, n_batches, args.warmup + args.steps, comm.world))
 
     def step(s, running):
+        # (batch number s x world + rank, around the space: a run longer than 2^64 / batch steps x ranks meets batches again)
         first = (base + (s * comm.world + comm.rank) * batch) % (1 << 64)
         r = eng.attract2(first, batch, MAX_T)
         running.append(r)

@@ -1,5 +1,5 @@
 """Sum rocprofv3 --pmc counters per launch of one kernel from the CSVs under a directory and derive what bounds it.
-usage: python tools/pmc_read.py <dir with pmc_*/ sub-directories and pmc_*.json bench lines> [kernel-substring] [log2_batch]
+usage: python tools/pmc_read.py <dir with pmc_*/ sub-directories and pmc_*.json bench lines> [kernel-substring] [log2_batch] [all]
 Writes one JSON object (profiles/<tag>_pmc.json is a copy of it; bench.py reads `per_executed_update`, `shader_clock_hz`,
 `hbm_bytes_per_launch` and `issue_bound` from there).  Counters are summed over the device; per launch = the LARGEST
 launches of the kernel (the top level of every cascade, which is what bench.py times as the dominant kernel).
@@ -16,6 +16,10 @@ import sys
 root = sys.argv[1]
 needle = sys.argv[2] if len(sys.argv) > 2 else 'k_attract_pool'
 log2_batch = int(sys.argv[3]) if len(sys.argv) > 3 else None
+# 'all': average over every launch of the kernel (the bench's PMC passes run without warm-up steps, so the launches the
+# counters see are exactly the ones whose updates and durations the bench line of the same pass adds up: the top level of
+# every sub-block's cascade, of different sizes); default: the largest launches only
+every_launch = len(sys.argv) > 4 and sys.argv[4] == 'all'
 per = collections.defaultdict(dict)      # counter -> dispatch id -> value
 for f in sorted(glob.glob(root + '/pmc_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
@@ -26,7 +30,7 @@ for f in sorted(glob.glob(root + '/pmc_*/**/*counter_collection.csv', recursive=
 out = {'kernel': needle, 'log2_batch': log2_batch, 'counters_per_launch': {}, 'launches_seen': {}}
 for name, by in per.items():
     vals = sorted(by.values())
-    big = [v for v in vals if v >= 0.5 * vals[-1]] or vals         # the dominant launches only
+    big = vals if every_launch else ([v for v in vals if v >= 0.5 * vals[-1]] or vals)        # the dominant launches only
     out['counters_per_launch'][name] = sum(big) / len(big)
     out['launches_seen'][name] = len(big)
 c = out['counters_per_launch']
@@ -39,6 +43,7 @@ for f in sorted(glob.glob(root + '/pmc_*.json')):
 upd = [b['roofline']['executed_updates_per_launch'] for b in lines if 'roofline' in b]
 if upd:
     out['executed_updates_per_launch'] = sum(upd) / len(upd)
+    out['launches_per_bench_line'] = [b['roofline'].get('launches_timed') for b in lines if 'roofline' in b]
 if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
     out['hbm_bytes_per_launch'] = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
     out['hbm_note'] = 'FETCH_SIZE x 2 (gfx950 counts half of wide reads) + WRITE_SIZE, KiB -> bytes, separate passes'

@@ -17,7 +17,7 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
-PMC_CMD="python3 bench.py --no-cpu-baseline --steps 4 --warmup 1"
+PMC_CMD="python3 bench.py --no-cpu-baseline --steps 4 --warmup 0"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
@@ -25,7 +25,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   tag=$(echo $grp | tr ' ' '+')
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$tag" -o run -- $PMC_CMD > "$OUT/pmc_$tag.json" 2> "$OUT/pmc_$tag.err" || echo "pmc pass $tag failed"
 done
-python3 tools/pmc_read.py $OUT k_attract_pool 56 > $OUT/pmc.json
+python3 tools/pmc_read.py $OUT "true, false>" 60 all > $OUT/pmc.json
 cat $OUT/pmc.json
 if [ "$2" != "--bench-only" ]; then
   python3 tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
