@@ -546,8 +546,14 @@ CascadeShape cascade_shape(bsx_handle h, const CascadeEnv& env) {
 // (bsx_engine::near_seen; the top level and the levels below it apart: children of listed classes are far more often near a
 // cycle than classes at large), else a guess that grows with the depth.
 double near_fraction(const bsx_engine* h, uint32_t d, bool is_top) {
-    const double* seen = h->near_seen[is_top ? 0 : 1][std::min<uint32_t>(d, kMaxCubeLevels)];
-    if (seen[0] >= 1024.0) return std::min(1.0, seen[1] / seen[0]);
+    d = std::min<uint32_t>(d, kMaxCubeLevels);
+    const auto& seen = h->near_seen[is_top ? 0 : 1];
+    if (seen[d][0] >= 1024.0) return std::min(1.0, seen[d][1] / seen[d][0]);
+    // nothing seen at this depth: the nearest depth that has been, a factor of two per level (deeper = nearer to the cycles)
+    for (uint32_t off = 1; off <= kMaxCubeLevels; ++off) {
+        if (d > off && seen[d - off][0] >= 1024.0) return std::min(1.0, seen[d - off][1] / seen[d - off][0] * std::ldexp(1.0, (int)off));
+        if (d + off <= kMaxCubeLevels && seen[d + off][0] >= 1024.0) return std::min(1.0, seen[d + off][1] / seen[d + off][0] * std::ldexp(1.0, -(int)off));
+    }
     return is_top ? std::min(1.0, 0.0025 * std::ldexp(1.0, (int)d - 2)) : 0.1;
 }
 
@@ -916,6 +922,7 @@ int run_cubes(bsx_handle h, const CascadeEnv& env, const std::vector<Cube>& cube
         g_prof[0] += now_ms() - pt_plan;
         if (int rc = run_batch(h, env_part, sh, B, ptrs)) return rc;
         bool repeat = false;
+        const double pt_eval = now_ms();
         for (size_t q = 0; q < chains.size(); ++q) {
             MergedTable pass_table;
             u128 pass_none = 0, pass_ref = 0;
@@ -937,6 +944,7 @@ int run_cubes(bsx_handle h, const CascadeEnv& env, const std::vector<Cube>& cube
                 return BSX_OK;
             }
         }
+        g_prof[5] += now_ms() - pt_eval;
         if (repeat) {
             unsigned int known = 0;
             HIPCHK(h, hipMemcpy(&known, h->d_cc_count.p, sizeof(known), hipMemcpyDeviceToHost));
@@ -1023,27 +1031,29 @@ int run_block(bsx_handle h, const CascadeEnv& env, uint64_t d_lo, uint32_t a_bit
             for (const auto& l : tree) est += cube_cost_us(h, sh, d_lo, a_bits, l.first, l.second);
             return est;
         };
-        bool experienced = false;                   // has the handle seen how many classes the levels list?
-        for (uint32_t d = 0; d <= kMaxCubeLevels; ++d) experienced = experienced || h->near_seen[0][d][0] >= 1024.0;
+        double experience = 0;                      // top-level classes whose listing the handle has seen so far
+        for (uint32_t d = 0; d <= kMaxCubeLevels; ++d) experience += h->near_seen[0][d][0];
         auto grow = [&]() {
             const double t0 = now_ms();
             std::vector<SplitLeaf> fresh;
             plan_split(h, sh, d_lo, a_bits, forced, fresh);
             tree.clear();
             for (const SplitLeaf& l : fresh) tree.emplace_back(l.mask, l.vals);
-            h->split_learned[a_bits] = experienced;
+            h->split_learned[a_bits] = experience;
             if (std::getenv("BSX_DEBUG"))
-                std::fprintf(stderr, "[bsx] split tree for blocks of 2^%u: %zu leaves, planned in %.2f ms (%s list fractions)\n", a_bits, tree.size(),
-                             now_ms() - t0, experienced ? "measured" : "guessed");
+                std::fprintf(stderr, "[bsx] split tree for blocks of 2^%u: %zu leaves, planned in %.2f ms (list fractions from %.3g classes seen)\n", a_bits,
+                             tree.size(), now_ms() - t0, experience);
         };
+        const double pt_est = now_ms();
         const double whole = cube_cost_us(h, sh, d_lo, a_bits, 0, 0);
         bool use = false;
-        // (a tree grown on guesses is grown again once the levels' list fractions have been measured)
-        if (tree.empty() || (experienced && !h->split_learned[a_bits])) { grow(); use = tree.size() > 1; }
+        // (a tree grown on guesses, or on what small blocks showed, is grown again when the handle has seen 16 times more)
+        if (tree.empty() || experience > 16.0 * (h->split_learned[a_bits] + 1024.0)) { grow(); use = tree.size() > 1; }
         else if (tree.size() > 1) {
             use = forced || estimate() < 0.8 * whole;
             if (!use && a_bits >= 60) { grow(); use = tree.size() > 1; }
         }
+        g_prof[4] += now_ms() - pt_est;
         if (use) {
             std::vector<Cube> cubes(tree.size());
             bool eligible = true;
@@ -1371,8 +1381,8 @@ int attract_core(bsx_handle h, const bsx_index& first, u128 count, uint64_t max_
     if (int rc2 = drain_attractor_table(h, tot.merged)) return rc2;
     if (tot.merged.size() > cap) return fail(h, BSX_ERR_TABLE_FULL, "more distinct attractors than the caller's table capacity");
     if (std::getenv("BSX_PROFILE")) {
-        std::fprintf(stderr, "[bsx] profile: passes: setup %.3f, enqueue %.3f, wait %.3f (kernels %.3f); %u host syncs\n",
-                     g_prof[0], g_prof[1], g_prof[2], g_prof[3], tot.syncs);
+        std::fprintf(stderr, "[bsx] profile: passes: setup %.3f, enqueue %.3f, wait %.3f (kernels %.3f), split estimates %.3f, reading the counters %.3f; %u host syncs\n",
+                     g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], tot.syncs);
         for (double& v : g_prof) v = 0;
     }
     return BSX_OK;

@@ -122,7 +122,7 @@ struct bsx_engine {
     uint32_t flag_seq = 0;
     hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;
     std::vector<hipEvent_t> ev_chain;                   // pairs around the top-level (dominant) launch of every chain of a batch
-    std::map<uint32_t, bool> split_learned;             // ... grown with measured list fractions (near_seen), not guesses
+    std::map<uint32_t, double> split_learned;           // ... and how many classes' listing the handle had seen when it was grown (near_seen)
     std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> split_cache;    // block size -> leaves (fix mask, values) of its split tree
     // independent launches of one call side by side (target's cube passes): auxiliary streams, one counter block per launch
     hipStream_t aux[8] = {};
