@@ -22,7 +22,9 @@ Accounting (what each number counts):
   reference_equivalent_node_updates_per_s   n x (sum of the reference loop's stop times, model.py:201) / s:
                                         what a stepping implementation would have had to do.
   attractors_per_s                      problems resolved per second (BASELINE.json's second metric).
-  roofline                              what bounds the dominant kernel (the top-level k_attract_pool launch of every step):
+  roofline                              what bounds the dominant kernel -- whichever of the pool kernel's two builds took more device
+                                        time in this run, the top level of the cascades (<..,true,false>) or their lower levels
+                                        (<..,true,true>); the other one is under `other_build`:
                                         `bound` names the busiest unit of the PMC profile of THIS build (profiles/r03_pmc.json:
                                         VALU issue / LDS pipeline / SALU issue), `achieved` = that unit's instructions per
                                         second = its per-executed-update cost from the profile x the updates this run's
@@ -48,7 +50,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_NODE_UPDATE = 0.25    # read + write of the n-bit state per step = n/4 B
 MAX_T = 4096
-PMC_FILE = os.path.join('profiles', 'r03_pmc.json')     # written by tools/pmc_read.py from the --pmc passes
+PMC_FILE = os.path.join('profiles', 'r03_pmc.json')     # written by tools/pmc_read.py from the --pmc passes: top-level build
+PMC_FILE_LOWER = os.path.join('profiles', 'r03_pmc_lower.json')     # ... lower-level build
 
 
 def main():
@@ -137,8 +140,8 @@ def main():
     comm.barrier()
     eng.synchronize()
     t0 = time.perf_counter()
-    steps_ref = steps_exec = dom_exec = dom_launches = launches = syncs = 0
-    kernel_ms = dom_ms = 0.0
+    steps_ref = steps_exec = dom_exec = dom_launches = launches = syncs = low_exec = low_launches = 0
+    kernel_ms = dom_ms = low_ms = 0.0
     results = []
     for s in range(args.warmup, args.warmup + args.steps):
         st = step(s, results).stats
@@ -149,6 +152,9 @@ def main():
         dom_ms += st['dominant_ms']
         dom_exec += st['dominant_executed_steps']
         dom_launches += st['dominant_launches']
+        low_ms += st['lower_ms']
+        low_exec += st['lower_executed_steps']
+        low_launches += st['lower_launches']
         syncs += st['host_syncs']
     mine = merge_tables(checked(results))
     # the job's one data collective: per-rank tables -> every rank (RCCL all-gather over xGMI)
@@ -161,47 +167,65 @@ def main():
     if comm.rank == 0:
         problems = batch * args.steps * comm.world
         assert sum(e[1] for e in merged.values()) <= problems
-        # roofline of the dominant kernel (the top-level k_attract_pool launch of every step), rank 0, measured live:
-        # HIP events around those launches, the updates they executed from their own counters
-        kernel = 'k_attract_pool<{},{},{},true,false>'.format(info['state_words32'], info['mux_slots'], info['lut_mode'])
-        avg_launch_s = dom_ms / 1e3 / dom_launches
-        upd_per_launch = dom_exec / dom_launches
-        alg_bytes_per_launch = upd_per_launch * n * BYTES_PER_NODE_UPDATE
-        hbm_norm = alg_bytes_per_launch / avg_launch_s / 1e9
-        roof = {'bound': 'hbm-normalised', 'achieved': hbm_norm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_norm / HBM_PEAK_GBS,
-                'traffic': None, 'note': 'no PMC profile of this build at ' + PMC_FILE + ': only the normalised figure'}
-        ppath = os.path.join(ROOT, PMC_FILE)
-        if os.path.exists(ppath):
-            with open(ppath) as f:
-                pmc = json.load(f)
-            per_upd = pmc.get('per_executed_update') or {}
-            if pmc.get('log2_batch') == args.log2_batch and per_upd:
-                # busy cycles of a unit, summed over its instances on the device (1024 SIMDs issue VALU / SALU, 256 CUs have an LDS)
-                units = {'valu': ('valu_busy_cycles', 1024), 'salu': ('salu_busy_cycles', 1024), 'lds': ('lds_busy_cycles', 256)}
-                clock_hz = pmc.get('shader_clock_hz', 2.4e9)
-                rates = {}
-                for unit, (key, lanes) in units.items():
-                    if key in per_upd:
-                        ach = per_upd[key] * upd_per_launch / avg_launch_s
-                        rates[unit] = (ach, lanes * clock_hz)
-                if rates:
-                    unit = max(rates, key=lambda u: rates[u][0] / rates[u][1])
-                    ach, peak = rates[unit]
-                    roof = {'bound': {'valu': 'valu-issue', 'salu': 'salu-issue', 'lds': 'lds-pipeline'}[unit],
-                            'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'G busy unit-cycles/s',
-                            'frac': ach / peak,
-                            'traffic': pmc.get('hbm_bytes_per_launch'),
-                            'traffic_source': PMC_FILE + ' (separate rocprofv3 --pmc passes of this command, not measured in this run)',
-                            'all_units_frac': {u: r[0] / r[1] for u, r in rates.items()},
-                            'basis': 'busy cycles of the unit per executed update (PMC passes of this build, ' + PMC_FILE + ') x updates the '
-                                     'dominant launches executed in THIS run / their HIP-event duration; peak = instances of the unit x shader clock',
-                            'pmc_busy_fractions': pmc.get('issue_bound'), 'source': PMC_FILE}
-        roof.update({'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3, 'launches_timed': dom_launches,
-                     'executed_updates_per_launch': upd_per_launch,
-                     'hbm_normalised': {'achieved': hbm_norm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_norm / HBM_PEAK_GBS,
-                                        'alg_bytes_per_launch': alg_bytes_per_launch,
-                                        'basis': '0.25 B per EXECUTED node update (SURVEY 8d) x executed updates per launch / HIP-event '
-                                                 'launch time: a normalised rate, states stay in registers / LDS'}})
+        # roofline of the two builds of the pool kernel a step launches, rank 0, measured live: the top level of every
+        # cascade (HIP events around those launches) and the lower levels (the launches' own first-in / last-out device
+        # clock), the updates they executed from their own counters.  `roofline` is the one that took more device time.
+        def roofline_of(kernel, ms, n_launches, executed, pmc_file, timing):
+            avg_launch_s = ms / 1e3 / n_launches
+            upd_per_launch = executed / n_launches
+            alg_bytes_per_launch = upd_per_launch * n * BYTES_PER_NODE_UPDATE
+            hbm_norm = alg_bytes_per_launch / avg_launch_s / 1e9
+            roof = {'bound': 'hbm-normalised', 'achieved': hbm_norm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_norm / HBM_PEAK_GBS,
+                    'traffic': None, 'note': 'no PMC profile of this build at ' + pmc_file + ': only the normalised figure'}
+            ppath = os.path.join(ROOT, pmc_file)
+            if os.path.exists(ppath):
+                with open(ppath) as f:
+                    pmc = json.load(f)
+                per_upd = pmc.get('per_executed_update') or {}
+                if pmc.get('log2_batch') == args.log2_batch and per_upd:
+                    # busy cycles of a unit, summed over its instances on the device (1024 SIMDs issue VALU / SALU, 256 CUs have an LDS)
+                    units = {'valu': ('valu_busy_cycles', 1024), 'salu': ('salu_busy_cycles', 1024), 'lds': ('lds_busy_cycles', 256)}
+                    clock_hz = pmc.get('shader_clock_hz', 2.4e9)
+                    rates = {}
+                    for unit, (key, lanes) in units.items():
+                        if key in per_upd:
+                            rates[unit] = (per_upd[key] * upd_per_launch / avg_launch_s, lanes * clock_hz)
+                    if rates:
+                        unit = max(rates, key=lambda u: rates[u][0] / rates[u][1])
+                        ach, peak = rates[unit]
+                        roof = {'bound': {'valu': 'valu-issue', 'salu': 'salu-issue', 'lds': 'lds-pipeline'}[unit],
+                                'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'G busy unit-cycles/s',
+                                'frac': ach / peak,
+                                'traffic': pmc.get('hbm_bytes_per_launch'),
+                                'traffic_source': pmc_file + ' (separate rocprofv3 --pmc passes of this command, not measured in this run)',
+                                'all_units_frac': {u: r[0] / r[1] for u, r in rates.items()},
+                                'basis': 'busy cycles of the unit per executed update (PMC passes of this build, ' + pmc_file + ') x updates these '
+                                         'launches executed in THIS run / their duration; peak = instances of the unit x shader clock',
+                                'pmc_busy_fractions': pmc.get('issue_bound'), 'source': pmc_file}
+            roof.update({'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3, 'launches_timed': n_launches, 'device_ms_per_step': ms / args.steps,
+                         'timing': timing, 'executed_updates_per_launch': upd_per_launch,
+                         'hbm_normalised': {'achieved': hbm_norm, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_norm / HBM_PEAK_GBS,
+                                            'alg_bytes_per_launch': alg_bytes_per_launch,
+                                            'basis': '0.25 B per EXECUTED node update (SURVEY 8d) x executed updates per launch / '
+                                                     'launch time: a normalised rate, states stay in registers / LDS'}})
+            return roof
+
+        shape = (info['state_words32'], info['mux_slots'], info['lut_mode'])
+        roof_top = roofline_of('k_attract_pool<{},{},{},true,false>'.format(*shape), dom_ms, dom_launches, dom_exec, PMC_FILE,
+                               'HIP events around every top-level launch')
+        roof_low = None
+        if low_launches:
+            roof_low = roofline_of('k_attract_pool<{},{},{},true,true>'.format(*shape), low_ms, low_launches, low_exec, PMC_FILE_LOWER,
+                                   "every launch's own first-workgroup-in to last-workgroup-out time on the device's constant clock "
+                                   '(Counters::t_first_not / t_last); launches that found an empty list are not counted')
+            roof_low['unit_of_work'] = ('network updates the lower levels executed; the depth-1 level evaluates up to 2^14 children of a listed '
+                                        'class bit-sliced behind ONE update of the parent, so its work per update is not that of a per-child pass')
+        if roof_low and low_ms > dom_ms:
+            roof, other = roof_low, roof_top
+        else:
+            roof, other = roof_top, roof_low
+        if other:
+            roof['other_build'] = other
         out = {
             'metric': 'node-state-updates/s',
             'value': tot_exec * n / elapsed,

@@ -63,7 +63,8 @@ class Stats2(C.Structure):
     _fields_ = [('problems', U128), ('state_steps', U128), ('executed_steps', C.c_uint64),
                 ('kernel_ms', C.c_double), ('total_ms', C.c_double), ('dominant_ms', C.c_double),
                 ('dominant_executed_steps', C.c_uint64), ('dominant_launches', C.c_uint32),
-                ('kernel_launches', C.c_uint32), ('host_syncs', C.c_uint32), ('pad', C.c_uint32)]
+                ('kernel_launches', C.c_uint32), ('host_syncs', C.c_uint32), ('lower_launches', C.c_uint32),
+                ('lower_ms', C.c_double), ('lower_executed_steps', C.c_uint64)]
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_ if name != 'pad'}

@@ -64,6 +64,10 @@ extern "C" int bsx_create(bsx_handle* out, int device) {
         delete h;
         return BSX_ERR_NO_DEVICE;
     }
+    {
+        int khz = 0;        // rate of wall_clock64() on the device (100 MHz on gfx9)
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_clock_khz = (double)khz;
+    }
     if (std::strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {
         g_create_error = std::string("device is ") + h->prop.gcnArchName + ", this engine is built for gfx950 only";
         delete h;

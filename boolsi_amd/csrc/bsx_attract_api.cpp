@@ -42,6 +42,9 @@ struct Totals {
     double kernel_ms = 0.0, dominant_ms = 0.0;
     uint64_t dominant_exec = 0;
     uint32_t launches = 0, dominant_launches = 0, limit_hits = 0, syncs = 0;
+    double lower_ms = 0;                // cascades: the launches of the lower levels that had anything to do (device clock)
+    uint64_t lower_exec = 0;
+    uint32_t lower_launches = 0;
 };
 
 enum PassKind { kPassGeneral = 0, kPassLean = 1, kPassPool = 2 };
@@ -877,6 +880,13 @@ int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const
         tot.dominant_ms += ms_top;
         tot.dominant_exec += h->h_ctr[ch->ctr_base].steps_exec;
         ++tot.dominant_launches;
+        for (uint32_t i = 1; i < ch->top; ++i) {
+            const Counters& c = h->h_ctr[ch->ctr_base + i];
+            if (!c.t_last || !c.t_first_not) continue;      // (an empty list: every workgroup left at once)
+            tot.lower_ms += (double)(c.t_last - ~c.t_first_not) / h->wall_clock_khz;     // ticks -> ms
+            tot.lower_exec += c.steps_exec;
+            ++tot.lower_launches;
+        }
     }
     ++tot.launches;         // (k_publish)
     return BSX_OK;
@@ -896,6 +906,7 @@ int run_cubes(bsx_handle h, const CascadeEnv& env, const std::vector<Cube>& cube
     auto book_device_time = [&]() {                         // (device time and launches count whether or not the results are kept)
         tot.steps_exec += part.steps_exec; tot.kernel_ms += part.kernel_ms; tot.launches += part.launches;
         tot.dominant_ms += part.dominant_ms; tot.dominant_exec += part.dominant_exec; tot.dominant_launches += part.dominant_launches;
+        tot.lower_ms += part.lower_ms; tot.lower_exec += part.lower_exec; tot.lower_launches += part.lower_launches;
         tot.syncs += part.syncs; tot.limit_hits += part.limit_hits;
     };
     for (int attempt = 0; attempt < 32; ++attempt) {
@@ -1491,6 +1502,9 @@ extern "C" int bsx_run_attract2(bsx_handle h, bsx_u128 first_flat, bsx_u128 coun
         stats->dominant_ms = tot.dominant_ms;
         stats->dominant_executed_steps = tot.dominant_exec;
         stats->dominant_launches = tot.dominant_launches;
+        stats->lower_ms = tot.lower_ms;
+        stats->lower_executed_steps = tot.lower_exec;
+        stats->lower_launches = tot.lower_launches;
         stats->kernel_launches = tot.launches;
         stats->host_syncs = tot.syncs;
         stats->total_ms = now_ms() - t_begin;

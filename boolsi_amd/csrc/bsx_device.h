@@ -109,6 +109,9 @@ struct alignas(256) Counters {   // zeroed before every launch (a multiple of 25
     unsigned long long fix_cnt[64], fix_sl[64], fix_sl2[64];   // two's complement
     unsigned long long fix_none, fix_ref, fix_capfail;
     unsigned long long near_classes;    // deep cube pass: classes whose common state F^depth is a cycle state (listed, see AttractParams::near)
+    // cube passes: when the first workgroup with work started (stored complemented, so that zero = nobody did) and the last one
+    // ended, 100 MHz ticks of the device's constant clock: the launch's own duration without a pair of events around it
+    unsigned long long t_first_not, t_last;
     unsigned long long wave_iters;      // diagnostic: loop iterations summed over waves
     unsigned long long service_rounds;  // diagnostic
     unsigned long long diag[4];         // diagnostic (BSX_DIAG builds): pool kernel: classes kept after fresh stages,

@@ -44,6 +44,7 @@ struct bsx_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop{};
+    double wall_clock_khz = 1e5;        // device clock behind wall_clock64()
     std::string error;
 
     // network

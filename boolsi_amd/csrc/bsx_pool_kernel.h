@@ -107,6 +107,9 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             }
         }
     }
+    if constexpr (CUBE) {
+        if (threadIdx.x == 0 && !P.mirror_out) atomicMax(&P.ctr->t_first_not, ~(unsigned long long)wall_clock64());
+    }
     const NetView<NW, K, LM> nv = stage_network<NW, K, LM>(P.net, smem, smem_free);
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tp = P.sp.tp_origin;                     // uniform: no variations here
@@ -1065,6 +1068,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         if (ref) atomicAdd(&P.ctr->steps_ref, ref);
         if (wg_ctr[3]) atomicAdd(&P.ctr->steps_exec, wg_ctr[3]);
         if (wg_ctr[0]) atomicAdd(&P.ctr->n_none, wg_ctr[0]);
+        if constexpr (cube) atomicMax(&P.ctr->t_last, (unsigned long long)wall_clock64());
     }
 }
 

@@ -180,7 +180,9 @@ typedef struct {
     uint32_t dominant_launches;
     uint32_t kernel_launches;
     uint32_t host_syncs;           /* times the host waited for the device inside the call */
-    uint32_t pad;
+    uint32_t lower_launches;       /* launches of the cascades' lower levels that had classes to work on ... */
+    double   lower_ms;             /* ... their device time (first workgroup in to last one out, the device's 100 MHz clock) */
+    uint64_t lower_executed_steps; /* ... and the network updates they executed */
 } bsx_stats2;
 
 /* Same semantics and table contents as bsx_run_attract (which stays, for ranges whose sums fit 64 bits).

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert _lib.ATTR_REC.itemsize == 72
     assert _lib.PROBLEM_REC.itemsize == 56
     assert _lib.HIT.itemsize == 16
-    assert C.sizeof(_lib.U128) == 16 and C.sizeof(_lib.Stats2) == 88
+    assert C.sizeof(_lib.U128) == 16 and C.sizeof(_lib.Stats2) == 104
     assert _lib.ATTR_REC2.itemsize == 32 + 8 + 16 + 24 + 32
 
 

@@ -11,6 +11,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG --bench-only > $OUT.round.log 2>&1 || { tail -20 $OUT.round.log; exit 1; }
 cp $OUT/pmc.json profiles/r03_pmc.json
+cp $OUT/pmc_lower.json profiles/r03_pmc_lower.json
 python3 bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
 bash tools/profile_configs.sh $TAG/cfg config4 config5 chaotic > $OUT.cfg.log 2>&1 || { tail -20 $OUT.cfg.log; exit 1; }
 for k in config4 config5 chaotic; do cp $OUT/cfg/pmc_$k.json profiles/r03_pmc_$k.json; done

@@ -40,10 +40,21 @@ for f in sorted(glob.glob(root + '/pmc_*.json')):
         lines.append(json.loads(open(f).read().strip().splitlines()[-1]))
     except (ValueError, IndexError):
         pass
-upd = [b['roofline']['executed_updates_per_launch'] for b in lines if 'roofline' in b]
+def block(b):
+    """the roofline block of a bench line that is about this kernel (bench.py: `roofline` or its `other_build`)"""
+    r = b.get('roofline') or {}
+    want = needle.replace(' ', '')
+    for cand in (r, r.get('other_build') or {}):
+        if want in cand.get('kernel', '').replace(' ', ''):
+            return cand
+    return r if 'kernel' not in r else None
+
+
+lines = [b for b in lines if block(b)]
+upd = [block(b)['executed_updates_per_launch'] for b in lines]
 if upd:
     out['executed_updates_per_launch'] = sum(upd) / len(upd)
-    out['launches_per_bench_line'] = [b['roofline'].get('launches_timed') for b in lines if 'roofline' in b]
+    out['launches_per_bench_line'] = [block(b).get('launches_timed') for b in lines]
 if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
     out['hbm_bytes_per_launch'] = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
     out['hbm_note'] = 'FETCH_SIZE x 2 (gfx950 counts half of wide reads) + WRITE_SIZE, KiB -> bytes, separate passes'
@@ -79,7 +90,7 @@ if 'GRBM_GUI_ACTIVE' in c:
         for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS'):
             if k in c:
                 out['per_executed_update'][k.lower()] = c[k] / u
-    ms = [b['roofline']['avg_launch_ms'] for b in lines if 'roofline' in b]
+    ms = [block(b)['avg_launch_ms'] for b in lines]
     if ms:
         out['shader_clock_hz'] = cycles / (sum(ms) / len(ms) * 1e-3)
         out['clock_note'] = 'GRBM_GUI_ACTIVE / 8 XCDs / the launch duration of the same profiled runs'

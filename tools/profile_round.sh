@@ -26,6 +26,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$tag" -o run -- $PMC_CMD > "$OUT/pmc_$tag.json" 2> "$OUT/pmc_$tag.err" || echo "pmc pass $tag failed"
 done
 python3 tools/pmc_read.py $OUT "true, false>" 60 all > $OUT/pmc.json
+python3 tools/pmc_read.py $OUT "true, true>" 60 all > $OUT/pmc_lower.json
 cat $OUT/pmc.json
 if [ "$2" != "--bench-only" ]; then
   python3 tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
