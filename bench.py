@@ -170,6 +170,8 @@ def main():
         # roofline of the two builds of the pool kernel a step launches, rank 0, measured live: the top level of every
         # cascade (HIP events around those launches) and the lower levels (the launches' own first-in / last-out device
         # clock), the updates they executed from their own counters.  `roofline` is the one that took more device time.
+        busy_totals = []        # per build with a PMC profile: unit -> (busy unit-cycles of this run's launches, unit-cycles per second of the device)
+
         def roofline_of(kernel, ms, n_launches, executed, pmc_file, timing):
             avg_launch_s = ms / 1e3 / n_launches
             upd_per_launch = executed / n_launches
@@ -190,6 +192,7 @@ def main():
                     for unit, (key, lanes) in units.items():
                         if key in per_upd:
                             rates[unit] = (per_upd[key] * upd_per_launch / avg_launch_s, lanes * clock_hz)
+                    busy_totals.append({u: (per_upd[units[u][0]] * executed, units[u][1] * clock_hz) for u in rates})
                     if rates:
                         unit = max(rates, key=lambda u: rates[u][0] / rates[u][1])
                         ach, peak = rates[unit]
@@ -226,6 +229,19 @@ def main():
             roof, other = roof_top, roof_low
         if other:
             roof['other_build'] = other
+        if roof_low:
+            # The lower levels run on side streams next to the following chains' top levels, so the per-launch durations of
+            # the two builds overlap (they add up to more than the kernel time, and each launch shares the chip).  What the
+            # device as a whole did: busy cycles of both builds (PMC figures per executed update x the updates of this
+            # run) over the HIP-event kernel time of the steps.
+            dev = {}
+            for u in ('valu', 'salu', 'lds'):
+                if busy_totals and all(u in b for b in busy_totals):
+                    dev[u] = sum(b[u][0] for b in busy_totals) / (busy_totals[0][u][1] * kernel_ms / 1e3)
+            roof['device_level'] = {'busy_fraction_over_kernel_time': dev, 'kernel_ms_per_step': kernel_ms / args.steps,
+                                    'launch_ms_per_step_by_build': {'top': dom_ms / args.steps, 'lower': low_ms / args.steps},
+                                    'note': 'the two builds overlap on side streams (BSX_CUBE_STREAMS=1 serialises them: '
+                                            'profiles/r03_bench_serial.json); per-build launch durations include that sharing'}
         out = {
             'metric': 'node-state-updates/s',
             'value': tot_exec * n / elapsed,

@@ -114,6 +114,7 @@ extern "C" int bsx_destroy(bsx_handle h) {
     if (h->h_ctr_multi) (void)hipHostFree(h->h_ctr_multi);
     if (h->h_leaf) (void)hipHostFree(h->h_leaf);
     for (hipEvent_t e : h->ev_chain) (void)hipEventDestroy(e);
+    for (hipStream_t st : h->side) if (st) (void)hipStreamDestroy(st);
     if (h->ev_top0) (void)hipEventDestroy(h->ev_top0);
     if (h->ev_top1) (void)hipEventDestroy(h->ev_top1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

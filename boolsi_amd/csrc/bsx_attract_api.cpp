@@ -646,6 +646,7 @@ struct ChainBatch {
     size_t shmem = 0;
     Launch full{};
     uint64_t seg_cap = 0;
+    uint32_t n_side = 0;            // sets of list buffers in use; > 1: lower levels on that many side streams
 };
 
 // Mirror check + buffers for a batch of chains.  ok = false: the cached attractors do not fit the mirror (no cubes then).
@@ -675,10 +676,17 @@ int prepare_batch(bsx_handle h, const CascadeEnv& env, const std::vector<Chain*>
     const uint64_t list_cap = std::min<uint64_t>(kNearBytes / (4 * (nw + 1)), 1ull << top_bits);
     B.seg_cap = std::getenv("BSX_CUBE_NEAR_CAP") ? (uint64_t)std::max(1, std::atoi(std::getenv("BSX_CUBE_NEAR_CAP")))     // (tests: force the shallower restart)
                                                  : std::max<uint64_t>(64, list_cap / B.full.grid.x);
-    if (lists) {
-        HIPCHK(h, h->d_near_seg.reserve((size_t)B.full.grid.x * B.seg_cap * (nw + 1)));      // (state + the tag of its cycle)
-        HIPCHK(h, h->d_near_counts.reserve(B.full.grid.x));
-        HIPCHK(h, h->d_near_list.reserve((size_t)B.full.grid.x * B.seg_cap * (nw + 1)));
+    // the lower levels of consecutive chains run on side streams (BSX_CUBE_STREAMS=1: everything on the handle's stream)
+    uint32_t n_lists = 0;
+    for (const Chain* ch : chains) n_lists += (!ch->lv.empty() && ch->top > 1) ? 1u : 0u;
+    const char* st_env = std::getenv("BSX_CUBE_STREAMS");
+    B.n_side = std::min<uint32_t>(n_lists, (uint32_t)std::max(1, std::min((int)kSideStreams, st_env ? std::atoi(st_env) : (int)kSideStreams)));
+    if (B.n_side < 2) B.n_side = lists ? 1 : 0;
+    for (uint32_t sl = 0; sl < B.n_side; ++sl) {
+        HIPCHK(h, h->d_near_seg[sl].reserve((size_t)B.full.grid.x * B.seg_cap * (nw + 1)));      // (state + the tag of its cycle)
+        HIPCHK(h, h->d_near_counts[sl].reserve(B.full.grid.x));
+        HIPCHK(h, h->d_near_list[sl].reserve((size_t)B.full.grid.x * B.seg_cap * (nw + 1)));
+        if (B.n_side > 1 && !h->side[sl]) HIPCHK(h, hipStreamCreateWithFlags(&h->side[sl], hipStreamNonBlocking));
     }
     HIPCHK(h, h->d_unres.reserve((size_t)std::max(blocks, 1u) * kUnresCap * rec_words));
     ok = true;
@@ -686,8 +694,16 @@ int prepare_batch(bsx_handle h, const CascadeEnv& env, const std::vector<Chain*>
 }
 
 // The launches of one chain, enqueued on the handle's stream (nothing is waited for).
-int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const ChainBatch& B, Chain& ch) {
+// With side streams (B.n_side > 1) only the top level and the packing of its list run on the handle's stream; the lower levels
+// -- short launches that mostly wait on memory -- follow on side stream `slot`, next to the following chains' top levels.
+// slot_busy[slot] = the event behind the last chain that used the slot's list buffers.
+int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const ChainBatch& B, Chain& ch, uint32_t slot,
+                  std::vector<hipEvent_t>& slot_busy) {
     const uint32_t nw = h->net.nw, rec_words = nw + 3;
+    const bool side = B.n_side > 1 && ch.top > 1;
+    hipStream_t const main_st = h->stream, tail_st = side ? h->side[slot] : h->stream;
+    hipEvent_t* const ev = h->ev_chain.data() + 4 * (size_t)ch.index;       // top in, top out, hand-over, chain done
+    if (side && slot_busy[slot]) HIPCHK(h, hipStreamWaitEvent(main_st, slot_busy[slot], 0));   // (the buffers' previous user has finished)
     AttractParams Q0 = env.P;
     Q0.cc.lds_slots = B.slots;
     Q0.merge = 3;
@@ -708,8 +724,8 @@ int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, c
         Q.entry_shift = l.k_bits;
         Q.stragglers = h->d_unres.p + (size_t)(ch.ctr_base + i) * kUnresCap * rec_words;
         Q.stragglers_cap = kUnresCap * rec_words;
-        Q.near = l.depth > 1 ? h->d_near_seg.p : nullptr;
-        Q.near_counts = l.depth > 1 ? h->d_near_counts.p : nullptr;
+        Q.near = l.depth > 1 ? h->d_near_seg[slot].p : nullptr;
+        Q.near_counts = l.depth > 1 ? h->d_near_counts[slot].p : nullptr;
         Q.near_cap = l.depth > 1 ? B.seg_cap : 0;
         dim3 grid = B.full.grid;
         if (i == 0) {
@@ -725,10 +741,10 @@ int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, c
             else { Q.chunk_first = L.chunk; Q.chunk = L.chunk; }
             if (const char* c = std::getenv("BSX_CHUNK")) { Q.chunk = (uint32_t)std::max(64, std::atoi(c)); Q.chunk_first = Q.chunk; }
             ch.top_grid = grid;
-            HIPCHK(h, hipEventRecord(h->ev_chain[2 * ch.index], h->stream));
+            HIPCHK(h, hipEventRecord(ev[0], main_st));
         } else {
             Q.count = 0;
-            Q.entries = h->d_near_list.p;               // (packed by the k_compact_near before this launch)
+            Q.entries = h->d_near_list[slot].p;         // (packed by the k_compact_near before this launch)
             Q.level_in = h->d_level + ch.desc_base + i;
             Q.chunk = 0; Q.chunk_first = 0;
             // the lower-level build of the kernel: no pool, no rings (its LDS is the tables alone)
@@ -737,7 +753,7 @@ int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, c
             if (Q.lower_build && l.depth == 1 && !(std::getenv("BSX_CUBE_LEAF") && std::getenv("BSX_CUBE_LEAF")[0] == '0')) {
                 LeafProgram& prog = h->h_leaf[ch.index];
                 if (build_leaf_program(h, l.cube.rel, prog)) {
-                    HIPCHK(h, hipMemcpyAsync(h->d_leaf.p + ch.index, &prog, sizeof(LeafProgram), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(h, hipMemcpyAsync(h->d_leaf.p + ch.index, &prog, sizeof(LeafProgram), hipMemcpyHostToDevice, tail_st));
                     Q.leaf = h->d_leaf.p + ch.index;
                     Q.entry_shift = 0;                  // work items = the listed entries themselves
                     l.per_parent = true;
@@ -745,10 +761,20 @@ int enqueue_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, c
             }
         }
         const size_t shmem_here = Q.lower_build ? h->shmem + (size_t)B.slots * h->cache_stride + 32 + pool_lower_extra_bytes(nw) : B.shmem;
-        HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem_here, h->stream, Q));
-        if (i == 0) HIPCHK(h, hipEventRecord(h->ev_chain[2 * ch.index + 1], h->stream));
+        hipStream_t const st = i == 0 ? main_st : tail_st;
+        HIPCHK(h, launch_attract_pool((int)nw, (int)h->net.k_mux, h->lut_mode, grid, shmem_here, st, Q));
+        if (i == 0) HIPCHK(h, hipEventRecord(ev[1], main_st));
         if (l.depth > 1)
-            HIPCHK(h, launch_compact_near(h->d_near_seg.p, h->d_near_counts.p, grid.x, B.seg_cap, nw + 1, h->d_near_list.p, h->d_level + ch.desc_base + i + 1, h->stream));
+            HIPCHK(h, launch_compact_near(h->d_near_seg[slot].p, h->d_near_counts[slot].p, grid.x, B.seg_cap, nw + 1, h->d_near_list[slot].p,
+                                          h->d_level + ch.desc_base + i + 1, st));
+        if (i == 0 && side) {                           // the rest of the chain: on the side stream, behind the list
+            HIPCHK(h, hipEventRecord(ev[2], main_st));
+            HIPCHK(h, hipStreamWaitEvent(tail_st, ev[2], 0));
+        }
+    }
+    if (side) {
+        HIPCHK(h, hipEventRecord(ev[3], tail_st));
+        slot_busy[slot] = ev[3];
     }
     return BSX_OK;
 }
@@ -774,8 +800,7 @@ int evaluate_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, 
                          (unsigned long long)classes, (unsigned long long)c.near_classes, (unsigned long long)c.straggler_classes);
         if (c.straggler_overflow) { verdict = kChainGiveUp; return BSX_OK; }      // too many unresolved classes: not a space for cubes
         if (c.near_overflow) { verdict = kChainLower; lower_to = l.depth - 1; return BSX_OK; }     // start over, shallower
-        // a level whose classes mostly sit next to a cycle only adds work: later blocks stop above it
-        if (l.depth > 1 && 2 * c.near_classes > classes) h->cube_depth_cap = l.depth - 1;
+        // (how many classes a level lists feeds the estimate that chooses later chains' tops: near_seen below)
         n_entries = c.near_classes;
         {
             double* seen = h->near_seen[i == 0 ? 0 : 1][std::min<uint32_t>(l.depth, kMaxCubeLevels)];
@@ -848,7 +873,7 @@ int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const
     }
     if (!n_live) return BSX_OK;
     if (blocks > kMaxChainBlocks || n_live > kMaxChains) return fail(h, BSX_ERR_INVALID, "internal: too many chains in one batch");
-    while (h->ev_chain.size() < 2 * (size_t)n_live) {
+    while (h->ev_chain.size() < 4 * (size_t)n_live) {
         hipEvent_t e = nullptr;
         HIPCHK(h, hipEventCreate(&e));
         h->ev_chain.push_back(e);
@@ -859,7 +884,16 @@ int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const
     // (descriptors and the counter blocks are one stretch of memory: one fill)
     HIPCHK(h, hipMemsetAsync(h->d_level, 0, kLevelDescBytes + sizeof(Counters) * blocks, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    for (Chain* ch : chains) if (!ch->lv.empty()) if (int rc = enqueue_chain(h, env, sh, B, *ch)) return rc;
+    {
+        std::vector<hipEvent_t> slot_busy(std::max(1u, B.n_side), nullptr);
+        uint32_t n_listing = 0;                         // chains with lower levels so far: they take the slots in turn
+        for (Chain* ch : chains) {
+            if (ch->lv.empty()) continue;
+            const uint32_t slot = (B.n_side > 1 && ch->top > 1) ? n_listing++ % B.n_side : 0u;
+            if (int rc = enqueue_chain(h, env, sh, B, *ch, slot, slot_busy)) return rc;
+        }
+        for (hipEvent_t e : slot_busy) if (e) HIPCHK(h, hipStreamWaitEvent(h->stream, e, 0));      // join
+    }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     const double pt1 = now_ms();
     if (int rc = fetch_counters(h, blocks)) return rc;
@@ -875,7 +909,7 @@ int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const
     for (Chain* ch : chains) {
         if (ch->lv.empty()) continue;
         float ms_top = 0.f;
-        HIPCHK(h, hipEventElapsedTime(&ms_top, h->ev_chain[2 * ch->index], h->ev_chain[2 * ch->index + 1]));
+        HIPCHK(h, hipEventElapsedTime(&ms_top, h->ev_chain[4 * ch->index], h->ev_chain[4 * ch->index + 1]));
         tot.launches += 2 * ch->top - 1;
         tot.dominant_ms += ms_top;
         tot.dominant_exec += h->h_ctr[ch->ctr_base].steps_exec;

@@ -162,6 +162,7 @@ struct LevelDesc {
     unsigned int pad;
 };
 constexpr uint32_t kMaxCubeLevels = 16;     // levels of one cascade
+constexpr uint32_t kSideStreams = 4;        // streams the lower levels of a batch's chains are spread over
 constexpr uint32_t kMaxChains = 48;         // cascades (sub-blocks of a split block) enqueued behind one wait
 constexpr uint32_t kMaxChainBlocks = 160;   // ... and their levels together = Counters blocks per wait
 constexpr size_t kLevelDescBytes = 3584;    // the descriptors' share of the counter buffer (a multiple of the Counters alignment)

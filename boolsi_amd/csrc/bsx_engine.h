@@ -82,9 +82,11 @@ struct bsx_engine {
     bsx::DevBuf<uint32_t> d_mirror;     // pool kernel: image of the LDS cache mirror, valid for (image_n journal records, image_slots slots)
     size_t image_n = ~size_t(0);
     uint32_t image_slots = 0;
-    bsx::DevBuf<uint32_t> d_near_seg;   // deep cube passes: classes listed for the level below, one segment per workgroup,
-    bsx::DevBuf<uint32_t> d_near_counts;    // the segments' fill counts,
-    bsx::DevBuf<uint32_t> d_near_list;  // and the packed list the next level reads
+    // deep cube passes, one set per side stream (the lower levels of up to kSideStreams chains run side by side):
+    bsx::DevBuf<uint32_t> d_near_seg[bsx::kSideStreams];    // classes listed for the level below, one segment per workgroup,
+    bsx::DevBuf<uint32_t> d_near_counts[bsx::kSideStreams]; // the segments' fill counts,
+    bsx::DevBuf<uint32_t> d_near_list[bsx::kSideStreams];   // and the packed list the next level reads
+    hipStream_t side[bsx::kSideStreams] = {};
     bsx::DevBuf<uint32_t> d_unres;      // cascade: unresolved classes per level (state, t, member count)
     bsx::DevBuf<bsx::LeafProgram> d_leaf;   // cascade: the depth-1 level's per-parent program (bsx_device.h)
     bsx::LeafProgram* h_leaf = nullptr;     // ... its pinned staging copy

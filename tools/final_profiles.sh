@@ -13,6 +13,7 @@ bash tools/profile_round.sh $TAG --bench-only > $OUT.round.log 2>&1 || { tail -2
 cp $OUT/pmc.json profiles/r03_pmc.json
 cp $OUT/pmc_lower.json profiles/r03_pmc_lower.json
 python3 bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
+BSX_CUBE_STREAMS=1 python3 bench.py --no-cpu-baseline > $OUT/bench_serial.json 2> $OUT/bench_serial.err      # (no side streams: clean per-build launch times)
 bash tools/profile_configs.sh $TAG/cfg config4 config5 chaotic > $OUT.cfg.log 2>&1 || { tail -20 $OUT.cfg.log; exit 1; }
 for k in config4 config5 chaotic; do cp $OUT/cfg/pmc_$k.json profiles/r03_pmc_$k.json; done
 python3 tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
