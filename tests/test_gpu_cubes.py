@@ -25,7 +25,7 @@ def eng():
     e = Engine(0)
     yield e
     e.close()
-    for k in ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_SPLIT'):
+    for k in ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_SPLIT', 'BSX_CUBE_STREAMS'):
         os.environ.pop(k, None)
 
 
@@ -319,9 +319,12 @@ def test_forced_levels_with_a_warm_up(eng, depth):
 
 # ---- sub-blocks: a block split along well-chosen relevant digits (BSX_CUBE_SPLIT=1 forces an eight-leaf tree on any block) ----
 
+@pytest.mark.parametrize('streams', [None, '1', '2'])
 @pytest.mark.parametrize('depth', [None, '2', '4'])
-def test_sub_blocks_vs_oracle_on_the_north_star(eng, depth):
+def test_sub_blocks_vs_oracle_on_the_north_star(eng, depth, streams):
     os.environ['BSX_CUBE_SPLIT'] = '1'
+    if streams:
+        os.environ['BSX_CUBE_STREAMS'] = streams         # (default: the lower levels of the chains on four side streams)
     if depth:
         os.environ['BSX_CUBE_DEPTH'] = depth
     net, space = setup(eng, synth.north_star_yaml())
