@@ -361,6 +361,7 @@ extern "C" int bsx_set_problem_space(bsx_handle h, const uint64_t* origin_state_
     h->fast_ok = true;
     h->split_cache.clear();
     h->split_learned.clear();
+    h->split_regrown.clear();
     std::memset(h->near_seen, 0, sizeof(h->near_seen));
     h->cube_depth_cap = 0;
     h->life_valid = 0;

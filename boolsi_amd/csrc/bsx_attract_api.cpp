@@ -545,7 +545,8 @@ CascadeShape cascade_shape(bsx_handle h, const CascadeEnv& env) {
 // enumerates 2^r_top classes at (top + 0.3) updates each; of the classes of level d + 1 the fraction f(d + 1) is listed, and
 // each listed class has 2^(r_d - r_(d + 1)) children at level d.  Rates as measured on the north star (profiles/r03_levels.md):
 // 4.5e11 class updates per second in the per-child passes, 1.5e12 children per second in the depth-1 level per parent,
-// kLevelOverheadUs for every level that has anything to do.  f is what this handle has seen at that depth so far
+// kLevelOverheadUs for every level that has anything to do.  (A least-squares fit over 107 per-parent levels says 95 us +
+// 1.75e12 children/s; pricing that latency in made the trees worse -- more, smaller chains -- on every block size tried.)  f is what this handle has seen at that depth so far
 // (bsx_engine::near_seen; the top level and the levels below it apart: children of listed classes are far more often near a
 // cycle than classes at large), else a guess that grows with the depth.
 double near_fraction(const bsx_engine* h, uint32_t d, bool is_top) {
@@ -914,6 +915,21 @@ int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const
         tot.dominant_ms += ms_top;
         tot.dominant_exec += h->h_ctr[ch->ctr_base].steps_exec;
         ++tot.dominant_launches;
+        if (std::getenv("BSX_DEBUG")) {             // the estimate against what the chain took, level by level
+            std::string line;
+            double sum = ms_top * 1e3;
+            char buf[96];
+            std::snprintf(buf, sizeof buf, "d%u %.0f", ch->top, ms_top * 1e3);
+            line += buf;
+            for (uint32_t i = 1; i < ch->top; ++i) {
+                const Counters& c = h->h_ctr[ch->ctr_base + i];
+                const double us = (c.t_last && c.t_first_not) ? (double)(c.t_last - ~c.t_first_not) / h->wall_clock_khz * 1e3 : 0.0;
+                sum += us;
+                std::snprintf(buf, sizeof buf, " | d%u %.0f", ch->top - i, us);
+                line += buf;
+            }
+            std::fprintf(stderr, "[bsx] chain %u: estimated %.0f us, took %.0f us (%s)\n", ch->index, chain_cost_us(h, ch->rel_mask, ch->top), sum, line.c_str());
+        }
         for (uint32_t i = 1; i < ch->top; ++i) {
             const Counters& c = h->h_ctr[ch->ctr_base + i];
             if (!c.t_last || !c.t_first_not) continue;      // (an empty list: every workgroup left at once)
@@ -1096,7 +1112,8 @@ int run_block(bsx_handle h, const CascadeEnv& env, uint64_t d_lo, uint32_t a_bit
         if (tree.empty() || experience > 16.0 * (h->split_learned[a_bits] + 1024.0)) { grow(); use = tree.size() > 1; }
         else if (tree.size() > 1) {
             use = forced || estimate() < 0.8 * whole;
-            if (!use && a_bits >= 60) { grow(); use = tree.size() > 1; }
+            // (a large block the tree does not help gets its own -- a few times per block size, not for every block of a sweep)
+            if (!use && a_bits >= 60 && h->split_regrown[a_bits] < 2) { ++h->split_regrown[a_bits]; grow(); use = tree.size() > 1; }
         }
         g_prof[4] += now_ms() - pt_est;
         if (use) {

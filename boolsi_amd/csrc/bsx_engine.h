@@ -125,6 +125,7 @@ struct bsx_engine {
     uint32_t flag_seq = 0;
     hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;
     std::vector<hipEvent_t> ev_chain;                   // pairs around the top-level (dominant) launch of every chain of a batch
+    std::map<uint32_t, uint32_t> split_regrown;         // ... how often it was regrown because it did not fit a block
     std::map<uint32_t, double> split_learned;           // ... and how many classes' listing the handle had seen when it was grown (near_seen)
     std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> split_cache;    // block size -> leaves (fix mask, values) of its split tree
     // independent launches of one call side by side (target's cube passes): auxiliary streams, one counter block per launch

@@ -71,6 +71,17 @@ __device__ __forceinline__ void deposit_runs(const DevSpace& sp, uint64_t d, uin
     }
 }
 
+// Per-parent level (bsx_device.h: LeafProgram): a batch of 64 parents with all their children is a long piece of serial work
+// for one wave (0.15 ms at 512 children each) while most waves of a launch have nothing to do, so the children -- in units
+// of one 32-children word -- are shared out over a power of two of work items per batch, enough for two per wave.
+__device__ __forceinline__ uint32_t leaf_parts(uint32_t kb, unsigned long long listed, uint64_t n_waves) {
+    const uint32_t units = kb > 5u ? 1u << (kb - 5u) : 1u;
+    const uint64_t batches = (listed + 63ull) / 64ull;
+    uint32_t parts = 1;
+    while (parts < units && batches * parts < 2ull * n_waves) parts <<= 1;
+    return parts;
+}
+
 // CUBE = true: the cube-pass build of the kernel (P.merge == 3): member counts only, no member masks, no
 // per-problem records; kept apart so that neither build carries the other's registers.
 // LOWER = true (with CUBE): the build for the lower levels of a chained cascade -- entry-based passes, whose classes are all
@@ -92,6 +103,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
         if (P.level_in) {                                   // uniform
             const unsigned long long listed = P.level_in->n_entries;
             n_items = P.level_in->abort ? 0ull : listed << P.entry_shift;
+            if constexpr (LOWER) {
+                // per-parent level: the children of a batch of 64 parents are shared out over `parts` work items (below)
+                if (P.leaf && n_items) n_items = ((listed + 63ull) & ~63ull) * leaf_parts(P.leaf->kb, listed, (uint64_t)gridDim.x * kPoolWaves);
+            }
             if (n_items == 0) {                             // nothing was handed down (or the level above overflowed)
                 if (threadIdx.x == 0 && P.near_counts) P.near_counts[blockIdx.x] = 0;
                 return;
@@ -412,12 +427,16 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             const uint32_t kb = L->kb, n_dep = L->n_dep;
             // (the children are taken 512 at a time: 16 words of 32; digits 9.. of the child index number the pieces)
             const uint32_t kb_in = kb < 9u ? kb : 9u;
-            const uint32_t n_pieces = 1u << (kb - kb_in);
             const uint32_t n_words = kb_in > 5u ? 1u << (kb_in - 5u) : 1u;                     // <= 16
             const uint32_t word_mask = kb_in >= 5u ? 0xFFFFFFFFu : (1u << (1u << kb_in)) - 1u;  // children in a word
             uint32_t indep[NW], added[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) { indep[w] = L->indep[w]; added[w] = L->added[w]; }
+            // work item = (parent, part of its children): items [part * listed64, (part + 1) * listed64) are part `part` of all parents
+            const unsigned long long listed = P.level_in->n_entries, listed64 = (listed + 63ull) & ~63ull;
+            const uint32_t parts = leaf_parts(kb, listed, (uint64_t)gridDim.x * kPoolWaves);
+            const uint32_t units_per_part = (kb > 5u ? 1u << (kb - 5u) : 1u) / parts;         // 32-children words
+            const uint32_t children_per_part = kb > 5u ? units_per_part * 32u : 1u << kb;
             for (;;) {
                 if (q.next == q.end) {
                     if (!q.more) break;
@@ -428,17 +447,24 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                 }
                 const uint64_t avail = q.end - q.next;
                 const uint32_t n = avail < 64u ? (uint32_t)avail : 64u;
-                const bool lv = lane < n;
+                const uint32_t part = (uint32_t)(q.next / listed64);                // uniform (shares are multiples of 64)
+                const unsigned long long pbase = q.next - (unsigned long long)part * listed64;
+                const bool lv = lane < n && pbase + lane < listed;
+                // this part's children: pieces [piece0, piece0 + n_pieces_here), of each the words [w0, w0 + n_words_here)
+                const uint32_t unit0 = part * units_per_part;
+                const uint32_t piece0 = unit0 >> 4, w0 = units_per_part >= 16u ? 0u : unit0 & 15u;
+                const uint32_t n_pieces_here = units_per_part >= 16u ? units_per_part >> 4 : 1u;
+                const uint32_t w_end = units_per_part >= 16u ? n_words : w0 + units_per_part;
                 uint32_t Sp[NW], Y[NW], tagp = 0;       // the parent's representative, its first update
 #pragma unroll
                 for (int w = 0; w < NW; ++w) { Sp[w] = 0; Y[w] = 0; }
                 if (lv) {
-                    const uint32_t* ent = P.entries + (q.next + lane) * (NW + 1);
+                    const uint32_t* ent = P.entries + (pbase + lane) * (NW + 1);
 #pragma unroll
                     for (int w = 0; w < NW; ++w) Sp[w] = ent[w];
                     tagp = ent[NW];
                     net_step<NW, K>(nv, Sp, fm0, fv0, Y, has_fixed);
-                    ++nexec;
+                    nexec += part == 0u ? 1u : 0u;      // (the other parts repeat it: not counted as work)
                 }
                 q.next += n;
                 uint32_t hits = 0;
@@ -454,7 +480,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                         uint32_t d0 = 0;
 #pragma unroll
                         for (int w = 0; w < NW; ++w) d0 |= (e[w] ^ Sp[w]) & ~added[w];
-                        if (lv && d0 == 0) {
+                        if (lv && d0 == 0 && part == 0u) {
                             const uint32_t lam0 = lamtab[(tagw & kTagMask) - 1];
                             account_fix(tagw, 0u, lam0, 1ll);
                             account_fix(tagw, 1u, lam0, -1ll);
@@ -468,10 +494,10 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     if (!__ballot(ok)) continue;
                     // the children whose first update is exactly this cycle state: dependent nodes, 32 children per word
                     uint32_t n_hit = 0;
-                    for (uint32_t piece = 0; piece < n_pieces; ++piece) {
+                    for (uint32_t piece = piece0; piece < piece0 + n_pieces_here; ++piece) {
                         uint32_t match[16];
 #pragma unroll
-                        for (int w = 0; w < 16; ++w) match[w] = (uint32_t)w < n_words ? word_mask : 0u;
+                        for (int w = 0; w < 16; ++w) match[w] = ((uint32_t)w >= w0 && (uint32_t)w < w_end) ? word_mask : 0u;
                         for (uint32_t di = 0; di < n_dep; ++di) {
                             const LeafDep dep = L->dep[di];                     // uniform
                             const uint32_t node = dep.node, k = dep.k;
@@ -485,7 +511,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                                 selp[j] = ((uint32_t)j < k && !(dep.in[j] & 0x8000u)) ? 0u - get_bit<NW>(Sp, dep.in[j]) : 0u;
 #pragma unroll
                             for (int w = 0; w < 16; ++w) {
-                                if ((uint32_t)w < n_words) {                    // uniform
+                                if ((uint32_t)w >= w0 && (uint32_t)w < w_end) { // uniform
                                     const uint32_t wg = piece * 16u + (uint32_t)w;     // the word's number among all children's
                                     uint32_t sel[kLeafMaxK];
 #pragma unroll
@@ -518,7 +544,7 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
                     if (n_hit) atomicAdd(&wave_cnt[2u * ((tagw & kTagMask) - 1u)], n_hit);
                     hits += n_hit;
                 }
-                if (lv) atomicAdd(&wave_cnt[2u * (tagp - 1u) + 1u], (1u << kb) - hits);
+                if (lv) atomicAdd(&wave_cnt[2u * (tagp - 1u) + 1u], children_per_part - hits);
             }
         } else {
 #ifndef BSX_LOWER_BATCHES
