@@ -319,8 +319,7 @@ def test_forced_levels_with_a_warm_up(eng, depth):
 
 # ---- sub-blocks: a block split along well-chosen relevant digits (BSX_CUBE_SPLIT=1 forces an eight-leaf tree on any block) ----
 
-@pytest.mark.parametrize('streams', [None, '1', '2'])
-@pytest.mark.parametrize('depth', [None, '2', '4'])
+@pytest.mark.parametrize('depth,streams', [(None, None), ('2', None), ('4', None), (None, '1'), ('4', '2')])
 def test_sub_blocks_vs_oracle_on_the_north_star(eng, depth, streams):
     os.environ['BSX_CUBE_SPLIT'] = '1'
     if streams:
@@ -347,7 +346,7 @@ def test_sub_blocks_vs_oracle_other_word_counts(eng, name, text, bits, log2n):
     same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << (log2n - 1)) + 99)
 
 
-@pytest.mark.parametrize('seed', range(48))
+@pytest.mark.parametrize('seed', range(32))
 def test_sub_blocks_equal_plain_enumeration_on_random_spaces(eng, seed):
     """Differential fuzz of split blocks: sparse networks, fixed nodes, tight caps, forced or free depths, short
     near-cycle lists (a sub-block restarts shallower on its own); against the plain enumeration."""
