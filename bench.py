@@ -48,6 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MAX_CLOCK_HZ = 2.4e9            # ... maximum shader clock
 BYTES_PER_NODE_UPDATE = 0.25    # read + write of the n-bit state per step = n/4 B
 MAX_T = 4096
 PMC_FILE = os.path.join('profiles', 'r03_pmc.json')     # written by tools/pmc_read.py from the --pmc passes: top-level build
@@ -187,7 +188,10 @@ def main():
                 if pmc.get('log2_batch') == args.log2_batch and per_upd:
                     # busy cycles of a unit, summed over its instances on the device (1024 SIMDs issue VALU / SALU, 256 CUs have an LDS)
                     units = {'valu': ('valu_busy_cycles', 1024), 'salu': ('salu_busy_cycles', 1024), 'lds': ('lds_busy_cycles', 256)}
-                    clock_hz = pmc.get('shader_clock_hz', 2.4e9)
+                    # peak = one busy cycle per unit per cycle of the 2.4 GHz maximum clock (MI355X_MICROARCH.md); the clock the chip
+                    # held is not measured here, so the fraction is a lower bound of the busy share (the PMC files' *_busy_frac
+                    # are against the cycles the launch really took)
+                    clock_hz = MAX_CLOCK_HZ
                     rates = {}
                     for unit, (key, lanes) in units.items():
                         if key in per_upd:
@@ -203,7 +207,7 @@ def main():
                                 'traffic_source': pmc_file + ' (separate rocprofv3 --pmc passes of this command, not measured in this run)',
                                 'all_units_frac': {u: r[0] / r[1] for u, r in rates.items()},
                                 'basis': 'busy cycles of the unit per executed update (PMC passes of this build, ' + pmc_file + ') x updates these '
-                                         'launches executed in THIS run / their duration; peak = instances of the unit x shader clock',
+                                         'launches executed in THIS run / their duration; peak = instances of the unit x the 2.4 GHz maximum clock',
                                 'pmc_busy_fractions': pmc.get('issue_bound'), 'source': pmc_file}
             roof.update({'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3, 'launches_timed': n_launches, 'device_ms_per_step': ms / args.steps,
                          'timing': timing, 'executed_updates_per_launch': upd_per_launch,
