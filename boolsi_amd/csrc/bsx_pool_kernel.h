@@ -432,6 +432,12 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
             uint32_t indep[NW], added[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) { indep[w] = L->indep[w]; added[w] = L->added[w]; }
+            // the dependent rules go to LDS (the prologue's list of cycle states inside the block is done with its 256 words): the
+            // loops below read one per (candidate, rule), and a scalar load from HBM there was most of a work item's latency
+            static_assert(sizeof(LeafDep) == 16 && kLeafMaxDeps * 4 <= kLowerFoundWords, "the rules fit the found list's words");
+            uint32_t* const dep_lds = midtab + 64 * NW;
+            for (uint32_t i = threadIdx.x; i < n_dep * 4u; i += blockDim.x) dep_lds[i] = reinterpret_cast<const uint32_t*>(L->dep)[i];
+            __syncthreads();
             // work item = (parent, part of its children): items [part * listed64, (part + 1) * listed64) are part `part` of all parents
             const unsigned long long listed = P.level_in->n_entries, listed64 = (listed + 63ull) & ~63ull;
             const uint32_t parts = leaf_parts(kb, listed, (uint64_t)gridDim.x * kPoolWaves);
@@ -499,7 +505,15 @@ __global__ __launch_bounds__(kPoolBlock, pool_min_waves(NW)) void k_attract_pool
 #pragma unroll
                         for (int w = 0; w < 16; ++w) match[w] = ((uint32_t)w >= w0 && (uint32_t)w < w_end) ? word_mask : 0u;
                         for (uint32_t di = 0; di < n_dep; ++di) {
-                            const LeafDep dep = L->dep[di];                     // uniform
+                            LeafDep dep;                                        // uniform (one broadcast read)
+                            {
+                                const uint32_t* const dw = dep_lds + 4u * di;
+                                const uint32_t d0w = __builtin_amdgcn_readfirstlane(dw[0]), d1w = __builtin_amdgcn_readfirstlane(dw[1]);
+                                const uint32_t d2w = __builtin_amdgcn_readfirstlane(dw[2]);
+                                dep.in[0] = (uint16_t)d0w; dep.in[1] = (uint16_t)(d0w >> 16); dep.in[2] = (uint16_t)d1w; dep.in[3] = (uint16_t)(d1w >> 16);
+                                dep.node = (uint16_t)d2w; dep.k = (uint16_t)(d2w >> 16);
+                                dep.tt = __builtin_amdgcn_readfirstlane(dw[3]);
+                            }
                             const uint32_t node = dep.node, k = dep.k;
                             uint32_t want_bit = 0;                              // this cycle state's value of the node (uniform)
 #pragma unroll
