@@ -19,7 +19,7 @@ from boolsi_amd.input import parse_input_text
 
 pytestmark = pytest.mark.gpu
 CORES = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-KNOBS = ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_LOWER', 'BSX_CUBE_LEAF', 'BSX_SPIN_WAIT')
+KNOBS = ('BSX_CUBES', 'BSX_CUBE_DEPTH', 'BSX_CUBE_NEAR_CAP', 'BSX_CUBE_LOWER', 'BSX_CUBE_LEAF', 'BSX_SPIN_WAIT', 'BSX_CUBE_SPLIT', 'BSX_CUBE_STREAMS')
 
 
 @pytest.fixture()
@@ -210,6 +210,29 @@ def test_the_general_build_and_the_plain_wait_give_the_same_tables(eng, knob):
         os.environ.pop(knob)
         assert merge_tables([a.table]) == merge_tables([b.table])
         assert a.n_no_attractor == b.n_no_attractor and a.stats['state_steps'] == b.stats['state_steps']
+
+
+@pytest.mark.parametrize('seed,k,log2', [(305, 2, 48), (310, 2, 48), (307, 2, 48), (309, 1, 56), (314, 2, 56), (316, 2, 56), (319, 2, 56)])
+def test_random_networks_at_scale_every_variant_of_the_cascade_agrees(eng, seed, k, log2):
+    """Sizes the oracle cannot reach, networks without a closed form: the engine as it comes (sub-blocks from 2^52 problems,
+    per-parent level, side streams) against forced sub-blocks, no sub-blocks, the per-child depth-1 level on one stream and
+    a forced depth on two -- identical tables, no-attractor counts and reference step counts (tools/fuzz_scale.py runs more
+    networks)."""
+    net, space = setup(eng, synth.network_yaml(64, k, seed), 4096)
+    first = ((0x9E3779B97F4A7C15 * (seed + 1)) % (1 << 64)) & ~((1 << log2) - 1)
+    ref = None
+    for env in ({}, {'BSX_CUBE_SPLIT': '1'}, {'BSX_CUBE_SPLIT': '0'}, {'BSX_CUBE_SPLIT': '1', 'BSX_CUBE_LEAF': '0', 'BSX_CUBE_STREAMS': '1'},
+                {'BSX_CUBE_SPLIT': '1', 'BSX_CUBE_DEPTH': '3', 'BSX_CUBE_STREAMS': '2'}):
+        for key in KNOBS:
+            os.environ.pop(key, None)
+        os.environ.update(env)
+        eng.set_problem(net, space)                      # (fresh experience for every variant)
+        r = eng.attract2(first, 1 << log2, 4096)
+        got = (merge_tables([r.table]), r.n_no_attractor, r.stats['state_steps'])
+        assert sum(e[1] for e in got[0].values()) + r.n_no_attractor == 1 << log2
+        if ref is None:
+            ref = got
+        assert got == ref, env
 
 
 @pytest.mark.parametrize('k,seed', [(1, 71), (2, 72), (3, 73), (4, 74), (4, 75)])
