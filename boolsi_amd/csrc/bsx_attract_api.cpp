@@ -996,8 +996,12 @@ int run_cubes(bsx_handle h, const CascadeEnv& env, const std::vector<Cube>& cube
                 part.steps_ref += pass_ref;
                 done[who[q]] = 1;
             } else if (verdict == kChainLower && lower_to >= 1) {
+                if (std::getenv("BSX_DEBUG"))
+                    std::fprintf(stderr, "[bsx] chain %u: a list overflowed, again from depth %u\n", chains[q].index, lower_to);
                 top[who[q]] = lower_to;
-                h->cube_depth_cap = lower_to;
+                // (a whole block remembers that for the rest of the problem; one sub-block of a dozen, whose lists are anybody's
+                // guess while the tree is grown on guesses, does not cap the others)
+                if (cubes.size() == 1) h->cube_depth_cap = lower_to;
             } else if (verdict == kChainRepeat) {
                 repeat = true;
             } else {                                        // not a space for cubes
