@@ -1112,8 +1112,8 @@ int run_block(bsx_handle h, const CascadeEnv& env, uint64_t d_lo, uint32_t a_bit
         const double pt_est = now_ms();
         const double whole = cube_cost_us(h, sh, d_lo, a_bits, 0, 0);
         bool use = false;
-        // (a tree grown on guesses, or on what small blocks showed, is grown again when the handle has seen 16 times more)
-        if (tree.empty() || experience > 16.0 * (h->split_learned[a_bits] + 1024.0)) { grow(); use = tree.size() > 1; }
+        // (a tree grown on guesses, or on what small blocks showed, is grown again when the handle has seen 64 times more)
+        if (tree.empty() || experience > 64.0 * (h->split_learned[a_bits] + 1024.0)) { grow(); use = tree.size() > 1; }
         else if (tree.size() > 1) {
             use = forced || estimate() < 0.8 * whole;
             // (a large block the tree does not help gets its own -- a few times per block size, not for every block of a sweep)
