@@ -45,6 +45,16 @@ def main():
         if probe.stats['executed_steps'] > (1 << 28) // 8 or probe.stats['kernel_ms'] > 50:
             print('seed {} K={}: does not collapse ({:.3e} updates for 2^28 problems), skipped'.format(seed, k, probe.stats['executed_steps']), flush=True)
             continue
+        if log2 > 48:       # (and a block 256 times smaller must be quick, or the block itself takes minutes)
+            eng = Engine(0)
+            eng.set_problem(net, space)
+            t0 = time.perf_counter()
+            eng.attract2(first, 1 << (log2 - 8), 4096)
+            dt = time.perf_counter() - t0
+            eng.close()
+            if dt > 0.25:
+                print('seed {} K={}: 2^{} problems already take {:.0f} ms, skipped'.format(seed, k, log2 - 8, dt * 1e3), flush=True)
+                continue
         ref = None
         for env in VARIANTS:
             for key in KNOBS:
