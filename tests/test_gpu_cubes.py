@@ -293,8 +293,8 @@ def test_deep_levels_equal_plain_enumeration_on_random_spaces(eng, seed):
                          ids=['config3', 'n128_k2', 'n200_k2', 'n48_k3'])
 def test_forced_levels_vs_oracle_other_word_counts(eng, name, text, bits, log2n, depth):
     """The level passes on states of 1, 4 and 8 words (the engine's own choice keeps blocks this small at one level)."""
-    if name == 'n48_k3' and depth == '2':
-        pytest.skip('slow oracle (long transients): the deepest setting covers this network')
+    if depth == '2' and name != 'config3':
+        pytest.skip('slow oracle: the deepest setting covers these networks (depth 2: config3 and the fuzz)')
     os.environ['BSX_CUBE_DEPTH'] = depth
     net, space = setup(eng, text)
     same_as_oracle(eng, net, space, 0, 1 << log2n)
@@ -328,11 +328,12 @@ def test_sub_blocks_vs_oracle_on_the_north_star(eng, depth, streams):
         os.environ['BSX_CUBE_DEPTH'] = depth
     net, space = setup(eng, synth.north_star_yaml())
     base = 0x0123456789ABCDEF & ~((1 << 28) - 1)
-    same_as_oracle(eng, net, space, base, 1 << 24)                           # (first contact with the attractors happens in sub-blocks)
-    g = same_as_oracle(eng, net, space, base + (1 << 24), 1 << 24)
+    g = same_as_oracle(eng, net, space, base, 1 << 24)                       # (first contact with the attractors happens in sub-blocks)
     assert g.stats['kernel_launches'] >= 8                                          # ... and there were several chains
     if streams or depth:
-        return                                                                   # (ragged ranges and caps: the engine's own depth, four streams)
+        return                                                                   # (more blocks, ragged ranges and caps: the engine's own depth, four streams)
+    g = same_as_oracle(eng, net, space, base + (1 << 24), 1 << 24)
+    assert g.stats['kernel_launches'] >= 8
     same_as_oracle(eng, net, space, base + (1 << 25) + 999, (1 << 23) + 12345)
     same_as_oracle(eng, net, space, 0, 1 << 23, max_t=12)
 
@@ -344,8 +345,7 @@ def test_sub_blocks_vs_oracle_other_word_counts(eng, name, text, bits, log2n):
     os.environ['BSX_CUBE_SPLIT'] = '1'
     os.environ['BSX_CUBE_DEPTH'] = '8'
     net, space = setup(eng, text)
-    same_as_oracle(eng, net, space, 0, 1 << log2n)
-    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << (log2n - 1)) + 99)
+    same_as_oracle(eng, net, space, (0x5DEECE66D << 7) % (1 << min(bits, 40)) | 1, (1 << log2n) + 99)      # (ragged on both sides)
 
 
 @pytest.mark.parametrize('seed', range(32))
