@@ -976,6 +976,18 @@ int run_cubes(bsx_handle h, const CascadeEnv& env, const std::vector<Cube>& cube
         uint32_t blocks = 0;
         for (Chain& ch : chains) { ptrs.push_back(&ch); blocks += ch.top; }
         if (blocks > kMaxChainBlocks || chains.size() > kMaxChains) { book_device_time(); return BSX_OK; }
+        // the chains whose lower levels are estimated to take longest go first: their tails run on the side streams while the
+        // others' top levels still keep the handle's stream busy, instead of being what the batch ends on
+        if (ptrs.size() > 2 && !(std::getenv("BSX_CUBE_ORDER_TAILS") && std::getenv("BSX_CUBE_ORDER_TAILS")[0] == '0')) {
+            auto tail_us = [&](const Chain* ch) {
+                const double top_us = kLevelOverheadUs + std::ldexp(1.0, __builtin_popcountll(ch->rel_mask[ch->top - 1])) * (ch->top + 0.3) / 4.5e5;
+                return chain_cost_us(h, ch->rel_mask, ch->top) - top_us;
+            };
+            std::vector<std::pair<double, Chain*>> keyed;
+            for (Chain* ch : ptrs) keyed.emplace_back(-tail_us(ch), ch);
+            std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<double, Chain*>& a, const std::pair<double, Chain*>& b) { return a.first < b.first; });
+            for (size_t i = 0; i < ptrs.size(); ++i) ptrs[i] = keyed[i].second;
+        }
         ChainBatch B;
         bool ok = false;
         if (int rc = prepare_batch(h, env_part, ptrs, B, ok)) return rc;
