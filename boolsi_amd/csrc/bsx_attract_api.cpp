@@ -791,7 +791,7 @@ int evaluate_chain(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, 
     uint64_t n_entries = 0;
     for (uint32_t i = 0; i < ch.top; ++i) {
         const ChainLevel& l = ch.lv[i];
-        const Counters c = h->h_ctr[ch.ctr_base + i];      // (a copy: the detector pass below reuses the first block)
+        const Counters& c = h->ctr_seen[ch.ctr_base + i];  // (the batch's blocks as fetched: the detector pass below reuses h_ctr's first)
         const uint64_t classes = i == 0 ? 1ull << l.k_bits : n_entries << l.k_bits;
         if (i > 0 && n_entries == 0) break;
         tot.steps_exec += c.steps_exec;
@@ -907,6 +907,9 @@ int run_batch(bsx_handle h, const CascadeEnv& env, const CascadeShape& sh, const
     }
     g_prof[1] += pt1 - pt0; g_prof[2] += pt2 - pt1; g_prof[3] += ms;
     tot.kernel_ms += ms;
+    // evaluate_chain reads this copy: a detector pass started for one chain's unresolved classes counts into h_ctr's first
+    // block again, which belongs to whichever chain was enqueued first -- not necessarily the one evaluated first
+    h->ctr_seen.assign(h->h_ctr, h->h_ctr + blocks);
     for (Chain* ch : chains) {
         if (ch->lv.empty()) continue;
         float ms_top = 0.f;

@@ -124,6 +124,7 @@ struct bsx_engine {
     volatile uint32_t* h_flag = nullptr;    // (behind h_ctr in the same pinned allocation)
     uint32_t flag_seq = 0;
     hipEvent_t ev_top0 = nullptr, ev_top1 = nullptr;
+    std::vector<bsx::Counters> ctr_seen;                // the counter blocks of the last batch of chains, as fetched
     std::vector<hipEvent_t> ev_chain;                   // pairs around the top-level (dominant) launch of every chain of a batch
     std::map<uint32_t, uint32_t> split_regrown;         // ... how often it was regrown because it did not fit a block
     std::map<uint32_t, double> split_learned;           // ... and how many classes' listing the handle had seen when it was grown (near_seen)
