@@ -25,11 +25,15 @@ Accounting (what each number counts):
   roofline                              what bounds the dominant kernel -- whichever of the pool kernel's two builds took more device
                                         time in this run, the top level of the cascades (<..,true,false>) or their lower levels
                                         (<..,true,true>); the other one is under `other_build`:
-                                        `bound` names the busiest unit of the PMC profile of THIS build (profiles/r03_pmc.json:
-                                        VALU issue / LDS pipeline / SALU issue), `achieved` = that unit's instructions per
-                                        second = its per-executed-update cost from the profile x the updates this run's
-                                        dominant launches executed / their HIP-event duration (measured live), `peak` =
-                                        1 instruction per cycle per SIMD (VALU, SALU) or per CU (LDS).
+                                        `bound` names the busiest unit of the PMC profile of THIS build (profiles/r03_pmc.json,
+                                        r03_pmc_lower.json: VALU issue / LDS pipeline / SALU issue), `achieved` = that unit's busy
+                                        cycles per second = its per-executed-update cost from the profile x the updates these
+                                        launches executed in this run / their duration (measured live: HIP events around the top
+                                        levels, the launches' own device clock for the lower levels), `peak` = one busy cycle per
+                                        cycle of the 2.4 GHz maximum clock per SIMD (VALU, SALU) or per CU (LDS).
+                                        `device_level`: the lower levels run on side streams next to the next chains' top levels,
+                                        so the two builds' launch durations overlap; this adds both builds' busy cycles over the
+                                        steps' kernel time (BSX_CUBE_STREAMS=1 serialises: profiles/r03_bench_serial.json).
                                         `hbm_normalised`: SURVEY 8(d)'s figure, 0.25 B per EXECUTED node update / launch time
                                         vs 8 TB/s -- a normalised rate, not HBM utilisation: states stay in registers / LDS,
                                         the measured HBM traffic (`traffic`) is orders of magnitude below it.
